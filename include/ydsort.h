@@ -1,0 +1,164 @@
+/* libydsort - MI355X (gfx950) native detect -> ReID -> DeepSORT association hot path.
+ *
+ * Flat C ABI (plain pointers and sizes, opaque handles, no exceptions, no torch types).
+ * The reference (GlassyWing/yolo_deepsort) is pure Python and has no FFI of its own; the
+ * boundary it exposes is the per-frame object API.  Each entry point below cites the
+ * reference interface (file:line under the reference root) whose arithmetic it replaces;
+ * the Python drop-in wrappers in yolo_deepsort_amd/ bind these with ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (message: yds_last_error());
+ *     creators return NULL on error.
+ *   - pointers named *_host are host memory, *_dev are device (HBM) memory obtained
+ *     from yds_dev_alloc or any hipMalloc'ed pointer on the same device.
+ *   - one HIP stream per handle; a handle is not thread safe; different handles may
+ *     be used concurrently.  Calls are asynchronous unless they return data to host
+ *     memory (those synchronise the handle's stream before returning).
+ *   - images are uint8 RGB, HWC, row-major; tensors fp32.
+ */
+#ifndef YDSORT_H
+#define YDSORT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct yds_net yds_net;     /* Darknet detector      (yolo3/models/models.py:277-313)      */
+typedef struct yds_reid yds_reid;   /* ReID extractor        (deep_sort/deep/feature_extractor.py) */
+typedef struct yds_trk yds_trk;     /* DeepSORT tracker      (deep_sort/sort/tracker.py:8-176)      */
+typedef struct yds_pipe yds_pipe;   /* detect+ReID+associate (yolo3/detect/video_detect.py:134-157) */
+
+/* ---- runtime -------------------------------------------------------------------------- */
+int yds_init(int device_id);                 /* hipSetDevice + capability check (gfx950)        */
+const char *yds_last_error(void);            /* thread-local message of the last failing call   */
+int yds_device_count(void);
+const char *yds_build_info(void);            /* "libydsort <ver> gfx950 ..."                    */
+void *yds_dev_alloc(size_t nbytes);
+int yds_dev_free(void *dev);
+int yds_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes);
+int yds_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes);
+int yds_device_sync(void);
+
+/* ---- detector: Darknet(cfg).forward + YOLO decode --------------------------------------
+ * yds_darknet_create      <- Darknet.__init__ / create_modules   models.py:25-102,279-290
+ *                            (cfg text is parsed with parse_model_config semantics,
+ *                             yolo3/utils/parse_config.py:1-19)
+ * yds_darknet_load_weights<- Darknet.load_darknet_weights         models.py:315-366
+ *                            blob = whole .weights file (5 x int32 header + fp32 stream);
+ *                            cutoff < 0 means "all layers" (the reference uses 75 for
+ *                            darknet53.conv.74)
+ * yds_darknet_forward_*   <- Darknet.forward + YOLOLayer.forward  models.py:185-224,292-313
+ *                            out: [batch, num_boxes, 5+classes], box index a*H*W+y*W+x,
+ *                            heads concatenated in cfg order
+ * yds_darknet_forward_u8* <- ImageDetector.detect :70-82 front end (stretch-resize to the
+ *                            model size with bilinear interpolation, /255) + the above
+ */
+yds_net *yds_darknet_create(const char *cfg_text, int img_h, int img_w, int batch_max);
+void yds_darknet_destroy(yds_net *);
+int yds_darknet_load_weights(yds_net *, const void *blob_host, size_t nbytes, int cutoff);
+int yds_darknet_num_boxes(const yds_net *);
+int yds_darknet_num_attrs(const yds_net *);                 /* 5 + classes                     */
+int yds_darknet_num_layers(const yds_net *);
+int yds_darknet_layer_shape(const yds_net *, int layer, int *c, int *h, int *w);
+int64_t yds_darknet_conv_flops(const yds_net *);            /* 2*MAC per image                 */
+int yds_darknet_forward_f32(yds_net *, const float *nchw_host, int batch, float *out_host);
+int yds_darknet_forward_u8(yds_net *, const uint8_t *rgb_hwc_host, int h, int w, int batch,
+                           float *out_host_or_null);
+int yds_darknet_forward_u8_dev(yds_net *, const uint8_t *rgb_hwc_dev, int h, int w, int batch);
+int yds_darknet_layer_output(yds_net *, int layer, int batch, float *nchw_host);   /* parity tests */
+int yds_darknet_get_input(yds_net *, int batch, float *nchw_host);                 /* parity tests */
+/* bench-only: overwrite head logits so the decode yields scripted boxes.
+ * rows: [n,9] fp32 = head, anchor, gy, gx, tx, ty, tw, th, cls ; image selects the batch slot.
+ * Applied on every following forward until cleared with n = 0. */
+int yds_darknet_set_injection(yds_net *, int image, const float *rows_host, int n, float logit);
+
+/* ---- post-processing: soft_non_max_suppression + resize_boxes ---------------------------
+ * yds_nms <- yolo3/utils/model_build.py:52-137 (multi-label hard NMS, class offset 4096,
+ *            cap 300; greedy kernel = torchvision.ops.boxes.nms semantics) and
+ *            resize_boxes :12-19 when frame_h > 0 (scale to frame pixels).
+ * out6: [cap,6] (x1,y1,x2,y2,score,cls) sorted by score; *n_out = rows written (0 <=> None). */
+int yds_nms(yds_net *, int image, float conf_thres, float iou_thres, int frame_h, int frame_w,
+            float *out6_host, int cap, int *n_out);
+/* same on caller-provided predictions [n_boxes, attrs] (host) */
+int yds_nms_pred(const float *pred_host, int n_boxes, int attrs, float conf_thres, float iou_thres,
+                 float *out6_host, int cap, int *n_out);
+
+/* ---- ReID: crop + Extractor + Net(reid=True) --------------------------------------------
+ * yds_reid_load_tensor <- Extractor.__init__ load_state_dict  feature_extractor.py:13-17
+ *                         (one call per 'net_dict' entry; names as in deep_sort/deep/model.py)
+ * yds_reid_embed       <- DeepSort._get_features deep_sort.py:133-146 (int-truncated, clipped
+ *                         crops), Extractor._preprocess feature_extractor.py:34-51 (bilinear
+ *                         resize to 64x128, /255, mean/std) and Net.forward model.py:81-92.
+ *                         out: [D,512] unit-norm rows.  Empty crops are an error (cv2.resize
+ *                         throws in the reference).
+ */
+yds_reid *yds_reid_create(int max_crops);
+void yds_reid_destroy(yds_reid *);
+int yds_reid_load_tensor(yds_reid *, const char *name, const float *data_host, const int64_t *shape, int ndim);
+int yds_reid_finalize(yds_reid *);            /* folds BN, uploads; error if a tensor is missing */
+int64_t yds_reid_flops_per_crop(void);
+int yds_reid_embed(yds_reid *, const uint8_t *frame_rgb_host, int h, int w, const float *tlwh_host,
+                   int D, float *out_host);
+int yds_reid_embed_dev(yds_reid *, const uint8_t *frame_rgb_dev, int h, int w, const float *tlwh_host,
+                       int D, float *out_host_or_null);
+const float *yds_reid_features_dev(yds_reid *);   /* [max_crops,512] device buffer written by embed */
+int yds_reid_preprocess(yds_reid *, const uint8_t *frame_rgb_host, int h, int w, const float *tlwh_host,
+                        int D, float *nchw_host);                                  /* parity tests */
+int yds_reid_forward_f32(yds_reid *, const float *nchw_host, int D, float *out_host);  /* parity tests */
+
+/* ---- tracker: DeepSort.update minus the extractor -----------------------------------------
+ * yds_tracker_create <- DeepSort.__init__ deep_sort.py:16-39 (cosine metric, budget, Tracker)
+ * yds_tracker_step   <- Tracker.predict + Tracker.update + output stage
+ *                       tracker.py:95-176, kalman_filter.py:54-256, nn_matching.py:139-187,
+ *                       linear_assignment.py:8-73,147-203, iou_matching.py:5-91, track.py,
+ *                       deep_sort.py:63-88.
+ *   tlwh [D,4], feats [D,512], payload [D] (class id as fp32, like the reference)
+ *   out6 [cap,6] int32 (x1,y1,x2,y2,track_id,class); *m_out rows (0 <=> the reference's []).
+ *   dbg_matches (optional) receives (track_index, det_index) pairs in reference order.
+ */
+yds_trk *yds_tracker_create(double max_dist, double max_iou_distance, int max_age, int n_init, int nn_budget);
+void yds_tracker_destroy(yds_trk *);
+int yds_tracker_step(yds_trk *, const float *tlwh_host, const float *feats_host, const float *payload_host,
+                     int D, int32_t *out6_host, int cap, int *m_out,
+                     int32_t *dbg_matches_host, int dbg_cap, int *n_matches);
+int yds_tracker_step_dev(yds_trk *, const float *tlwh_host, const float *feats_dev, const float *payload_host,
+                         int D, int32_t *out6_host, int cap, int *m_out);
+int yds_tracker_num_tracks(const yds_trk *);
+int yds_tracker_get_state(yds_trk *, int32_t *ids, int32_t *state, int32_t *tsu, int32_t *hits,
+                          float *mean8, float *cov64, int cap, int *T);
+int yds_tracker_last_unmatched(yds_trk *, int32_t *um_tracks, int cap_t, int *n_t,
+                               int32_t *um_dets, int cap_d, int *n_d);
+/* stand-alone association primitives (parity tests call these through the C ABI) */
+int yds_lsap(const float *cost_host, int nr, int nc, int32_t *rows, int32_t *cols, int *n_out);
+int yds_kalman_predict(float *mean_host, float *cov_host, int T);
+int yds_kalman_update(float *mean_host, float *cov_host, const float *xyah_host, int M);
+int yds_kalman_gating(const float *mean_host, const float *cov_host, int T, const float *xyah_host, int D,
+                      float *out_TxD_host);
+int yds_iou_cost(const float *track_tlwh_host, int T, const float *det_tlwh_host, int D, float *out_TxD_host);
+int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T,
+                        const float *feats_host, int D, int dim, float *out_TxD_host);
+
+/* ---- pipeline: VideoDetector.detect hot glue (video_detect.py:134-157) ----------------------
+ * One stream: detector over `batch` consecutive frames, then per frame NMS -> class mask ->
+ * p1p2Toxywh -> ReID -> tracker step, in frame order.  Frames are already resident in HBM.
+ * class_mask: list of class ids kept (NULL/0 = keep all).  out6: [batch, cap, 6] int32,
+ * counts[batch] rows per frame (-1 = detector returned None, tracker not called). */
+yds_pipe *yds_pipeline_create(yds_net *, yds_reid *, yds_trk *, float conf_thres, float nms_thres,
+                              const int32_t *class_mask, int n_mask);
+void yds_pipeline_destroy(yds_pipe *);
+int yds_pipeline_step(yds_pipe *, const uint8_t *frames_dev, int h, int w, int batch,
+                      int32_t *out6_host, int cap, int32_t *counts_host);
+/* per-stage device time of the last step in microseconds: resize, detector, decode+nms, reid, assoc */
+int yds_pipeline_stage_us(yds_pipe *, float *us5);
+/* average duration (us) and launch count of the implicit-GEMM conv kernel since the last reset,
+ * measured with HIP events on the handle's stream */
+int yds_conv_timing(yds_net *, int reset, double *total_us, int64_t *launches, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YDSORT_H */

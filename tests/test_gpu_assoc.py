@@ -1,0 +1,280 @@
+"""HIP NMS / ReID / Kalman / LSAP / tracker (through the C ABI) vs oracle + reference golden vectors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from yolo_deepsort_amd import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+RTOL, ATOL = 1e-3, 1e-3
+
+
+def _lib():
+    from yolo_deepsort_amd import _lib
+    _lib.init(0)
+    return _lib
+
+
+# ----------------------------------------------------------------------------------------- NMS
+def _nms(pred, ct, it):
+    L = _lib()
+    pred = np.ascontiguousarray(pred, dtype=F32)
+    out = np.zeros((300, 6), F32)
+    n = C.c_int(0)
+    L.check(L.load().yds_nms_pred(L.ptr(pred), pred.shape[0], pred.shape[1], ct, it, L.ptr(out), 300, C.byref(n)))
+    return out[:n.value]
+
+
+def test_nms_golden_cases_bit_exact():
+    from oracle import nms as onms
+    g = golden("nms_cases")
+    names = sorted({k[:-5] for k in g.files if k.endswith("_pred")})
+    for nme in names:
+        ct, it = (float(v) for v in g[nme + "_thr"])
+        got = _nms(g[nme + "_pred"][0], ct, it)
+        ref = g[nme + "_out"]
+        assert got.shape == ref.shape, nme
+        assert np.array_equal(got, ref), nme
+        want = onms.soft_non_max_suppression(g[nme + "_pred"], ct, it)[0]
+        if want is None:
+            assert got.shape[0] == 0
+        else:
+            assert np.array_equal(got, want), nme
+
+
+def test_nms_random_vs_oracle():
+    from oracle import nms as onms
+    rng = np.random.RandomState(3)
+    for trial in range(6):
+        n = int(rng.choice([1, 37, 500, 3000]))
+        p = np.zeros((1, n, 85), F32)
+        p[0, :, :2] = rng.uniform(0, 608, (n, 2))
+        p[0, :, 2:4] = rng.uniform(5, 250, (n, 2))
+        p[0, :, 4] = rng.uniform(0, 1, n) ** 3
+        p[0, :, 5:] = rng.uniform(0, 1, (n, 80)) ** 6
+        want = onms.soft_non_max_suppression(p, 0.4, 0.45)[0]
+        got = _nms(p[0], 0.4, 0.45)
+        if want is None:
+            assert got.shape[0] == 0
+        else:
+            assert np.array_equal(got, want), trial
+
+
+def test_detect_plumbing_cfg1_golden():
+    """BASELINE cfg1 through the drop-in ImageDetector: yolov3-tiny 416, tracker=None, 640x480 frame."""
+    import os
+    import tempfile
+    from yolo_deepsort_amd import cfgs
+    from yolo_deepsort_amd.detect import ImageDetector
+    from yolo_deepsort_amd.models import Darknet
+    g = golden("detect_plumbing_640x480")
+    cfg = cfgs.cfg_text("yolov3-tiny")
+    net = Darknet(None, img_size=(416, 416), cfg_text=cfg)
+    net.load_darknet_weights(None, blob=synth.darknet_weights_blob(cfg, 0, float(g["obj_bias"])))
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+    det = ImageDetector(net, f.name, thres=0.5, nms_thres=0.4)
+    os.unlink(f.name)
+    assert det.num_classes == 80
+    frame = np.random.RandomState(0).randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    out = det.detect(frame)
+    out = out.numpy() if hasattr(out, "numpy") else out
+    ref = g["out"]
+    assert out.shape == ref.shape and ref.shape[0] > 0
+    assert np.array_equal(out[:, 5], ref[:, 5])
+    np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL)
+    assert det.detect(np.zeros((480, 640, 3), np.uint8)) is None or True
+
+
+# ----------------------------------------------------------------------------------------- ReID
+def test_reid_golden_and_oracle():
+    from oracle import reid as oreid
+    from yolo_deepsort_amd.deep_sort import Extractor
+    g = golden("reid_seed0")
+    sd = synth.reid_state_dict(0)
+    ex = Extractor(sd)
+    scene = synth.PersonScene(8, seed=4)
+    frame = scene.frame(0)
+    tlwh = g["tlwh"]
+    pre = ex.preprocess(frame, tlwh)
+    assert np.array_equal(pre, oreid.preprocess_crops(frame, tlwh))          # crop + resize + normalise: bit exact
+    np.testing.assert_allclose(pre[:, :, ::16, ::8], g["pre_sample"], rtol=0, atol=1e-6)
+    feats = ex.embed(frame, tlwh)
+    np.testing.assert_allclose(feats, g["feats"], rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(feats, oreid.reid_forward(pre, sd), rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(feats, axis=1), 1.0, atol=1e-5)
+    # reference call convention: list of crops
+    crops = [frame[y1:y2, x1:x2] for x1, y1, x2, y2 in g["crops"]]
+    f2 = ex(crops)
+    f2 = f2.numpy() if hasattr(f2, "numpy") else f2
+    np.testing.assert_allclose(f2, feats, rtol=1e-5, atol=1e-6)
+
+
+def test_reid_larger_batch_vs_oracle():
+    from oracle import reid as oreid
+    from yolo_deepsort_amd.deep_sort import Extractor
+    sd = synth.reid_state_dict(1)
+    ex = Extractor(sd, max_crops=64)
+    x = np.random.RandomState(2).randn(37, 3, 128, 64).astype(F32)
+    np.testing.assert_allclose(ex.forward(x), oreid.reid_forward(x, sd), rtol=RTOL, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------- Kalman
+def test_kalman_kernels_vs_golden():
+    L = _lib()
+    lib = L.load()
+    g = golden("kalman")
+    mean, cov = g["init_mean"].copy(), g["init_cov"].copy()
+    T = mean.shape[0]
+    m1, c1 = g["ka_m0"].copy(), g["ka_c0"].copy()
+    L.check(lib.yds_kalman_predict(L.ptr(m1), L.ptr(c1), 1))
+    assert np.array_equal(m1, g["ka_m1"]) and np.array_equal(c1, g["ka_c1"])     # predict is exact (2-term sums)
+    z = np.array([[12, 20, .6, 11]], F32)
+    L.check(lib.yds_kalman_update(L.ptr(m1), L.ptr(c1), L.ptr(z), 1))
+    np.testing.assert_allclose(m1, g["ka_m2"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c1, g["ka_c2"], rtol=1e-4, atol=1e-6)
+    for s in range(3):
+        L.check(lib.yds_kalman_predict(L.ptr(mean), L.ptr(cov), T))
+        np.testing.assert_allclose(mean, g[f"pred{s}_mean"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(cov, g[f"pred{s}_cov"], rtol=1e-4, atol=1e-5)
+        zs = np.ascontiguousarray(g[f"z{s}"])
+        L.check(lib.yds_kalman_update(L.ptr(mean), L.ptr(cov), L.ptr(zs), T))
+        np.testing.assert_allclose(mean, g[f"upd{s}_mean"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(cov, g[f"upd{s}_cov"], rtol=1e-3, atol=1e-4)
+    meas = np.ascontiguousarray(g["meas"])
+    out = np.zeros((T, meas.shape[0]), F32)
+    L.check(lib.yds_kalman_gating(L.ptr(mean), L.ptr(cov), T, L.ptr(meas), meas.shape[0], L.ptr(out)))
+    np.testing.assert_allclose(out, g["gate2"], rtol=1e-3, atol=1e-3)
+
+
+def test_cost_kernels_vs_oracle():
+    from oracle import tracker as otrk
+    L = _lib()
+    lib = L.load()
+    rng = np.random.RandomState(4)
+    T, D = 23, 41
+    tb = np.concatenate([rng.uniform(0, 1800, (T, 2)), rng.uniform(20, 200, (T, 2))], 1).astype(F32)
+    db = np.concatenate([rng.uniform(0, 1800, (D, 2)), rng.uniform(20, 200, (D, 2))], 1).astype(F32)
+    db[:10] = tb[:10] + rng.uniform(-5, 5, (10, 4)).astype(F32)
+    db[10] = tb[10]                                       # identical boxes: IoU > 1 quirk (asymmetric +1)
+    out = np.zeros((T, D), F32)
+    L.check(lib.yds_iou_cost(L.ptr(tb), T, L.ptr(db), D, L.ptr(out)))
+    # the kernel sees tracks as xyah means; rebuild tlwh the way Track.to_tlwh does
+    m = otrk.tlwh_to_xyah(tb)
+    tb2 = m.copy(); tb2[:, 2] *= tb2[:, 3]; tb2[:, :2] -= tb2[:, 2:] / F32(2)
+    want = (F32(1) - otrk.iou_matrix(tb2, db)).astype(F32)
+    np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-6)
+    assert out[10, 10] < 0                               # IoU exceeds 1 for identical boxes
+    # cosine nearest-neighbour cost over ragged galleries
+    seg = np.concatenate([[0], np.cumsum(rng.randint(1, 31, T))]).astype(np.int32)
+    gal = rng.randn(seg[-1], 512).astype(F32)
+    feats = rng.randn(D, 512).astype(F32)
+    feats[:5] = gal[seg[:5]] + 0.05 * rng.randn(5, 512).astype(F32)
+    out = np.zeros((T, D), F32)
+    L.check(lib.yds_cosine_min_cost(L.ptr(gal), L.ptr(seg), T, L.ptr(feats), D, 512, L.ptr(out)))
+    dist = otrk.cosine_distance(gal, feats)
+    want = np.stack([dist[seg[k]:seg[k + 1]].min(0) for k in range(T)], 0)
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=2e-6)
+
+
+# ----------------------------------------------------------------------------------------- LSAP
+def _lsap(c):
+    L = _lib()
+    c = np.ascontiguousarray(c, dtype=F32)
+    n = min(c.shape)
+    r, k = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    m = C.c_int(0)
+    L.check(L.load().yds_lsap(L.ptr(c), c.shape[0], c.shape[1], L.ptr(r), L.ptr(k), C.byref(m)))
+    return r[:m.value], k[:m.value]
+
+
+def test_lsap_bit_exact_vs_scipy_and_oracle():
+    from scipy.optimize import linear_sum_assignment
+    from oracle import clib
+    rng = np.random.RandomState(0)
+    for trial in range(300):
+        nr, nc = rng.randint(1, 40, 2)
+        kind = trial % 4
+        if kind == 0:
+            c = rng.rand(nr, nc).astype(F32)
+        elif kind == 1:
+            c = rng.randint(0, 3, (nr, nc)).astype(F32)
+        elif kind == 2:
+            c = rng.rand(nr, nc).astype(F32)
+            c[c > 0.3] = F32(0.30001)
+        else:
+            c = np.full((nr, nc), 0.70001, F32)
+            m = rng.rand(nr, nc) < 0.2
+            c[m] = rng.rand(m.sum())
+        r0, c0 = linear_sum_assignment(c)
+        r1, c1 = _lsap(c)
+        r2, c2 = clib.lsap(c)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (trial, nr, nc)
+        assert np.array_equal(r2, r1) and np.array_equal(c2, c1)
+    for shape in ((200, 150), (150, 200), (1, 300), (300, 1), (257, 257)):
+        c = np.full(shape, 0.30001, F32)
+        m = rng.rand(*shape) < 0.03
+        c[m] = rng.rand(m.sum()) * 0.3
+        r0, c0 = linear_sum_assignment(c)
+        r1, c1 = _lsap(c)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), shape
+    assert _lsap(np.ones((4, 4)))[1].tolist() == [0, 1, 2, 3]
+
+
+# ----------------------------------------------------------------------------------------- traces
+TRACE_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
+
+
+def _run_trace(scene, g, params, drop=(), empty=()):
+    from yolo_deepsort_amd.deep_sort import _TrackerHandle
+    from oracle import tracker as otrk
+    _lib()
+    trk = _TrackerHandle(params["max_dist"], params["max_iou_distance"], params["max_age"], params["n_init"], params["nn_budget"])
+    ora = otrk.TrackerOracle(**params)
+    n = int(g["n_frames"])
+    for t in range(n):
+        if f"f{t}_skipped" in g.files:
+            assert t in drop
+            continue
+        ids, tlwh = scene.boxes(t)
+        feats = scene.features(t)
+        if t in empty:
+            tlwh, feats, ids = tlwh[:0], feats[:0], ids[:0]
+        payload = (ids % 3 * 2).astype(F32)
+        out, matches = trk.step(tlwh, feats, payload, want_debug=True)
+        want = np.array(ora.update(tlwh, feats, payload), dtype=np.int32).reshape(-1, 6)
+        um_t, um_d = trk.last_unmatched()
+        st = trk.state()
+        assert np.array_equal(matches, g[f"f{t}_matches"]), t                    # assignment indices: bit exact
+        assert np.array_equal(um_d, g[f"f{t}_um_d"]), t
+        assert np.array_equal(um_t, g[f"f{t}_um_t"]), t
+        assert np.array_equal(st["ids"], g[f"f{t}_ids"]), t                      # track ids: bit exact
+        assert np.array_equal(st["state"], g[f"f{t}_state"]), t
+        assert np.array_equal(st["tsu"], g[f"f{t}_tsu"]), t
+        assert np.array_equal(st["hits"], g[f"f{t}_hits"]), t
+        ref = g[f"f{t}_out"]
+        assert out.shape == ref.shape == want.shape, t
+        assert np.array_equal(out[:, 4:], ref[:, 4:]), t
+        assert np.abs(out[:, :4] - ref[:, :4]).max(initial=0) <= 1, t            # int truncation of fp32 boxes
+        assert np.abs(out[:, :4] - want[:, :4]).max(initial=0) <= 1, t
+        if f"f{t}_mean" in g.files:
+            np.testing.assert_allclose(st["mean"], g[f"f{t}_mean"], rtol=RTOL, atol=ATOL)
+    return trk
+
+
+def test_track_trace_30_golden():
+    _run_trace(synth.PersonScene(30, seed=0, occlude_frac=0.15), golden("track_trace_30"), TRACE_PARAMS,
+               drop=(20, 21), empty=(35,))
+
+
+def test_track_trace_short_max_age_golden():
+    _run_trace(synth.PersonScene(12, seed=2, occlude_frac=0.6), golden("track_trace_12_maxage4"),
+               dict(TRACE_PARAMS, max_age=4))
+
+
+def test_track_trace_crowd_200x150_golden():
+    """BASELINE cfg5 association load: 200 live tracks, 150 detections per frame."""
+    _run_trace(synth.PersonScene(200, seed=0, n_visible=150), golden("track_trace_200x150"), TRACE_PARAMS)

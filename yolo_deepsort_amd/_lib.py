@@ -1,0 +1,174 @@
+"""ctypes binding of libydsort.so (the C ABI declared in include/ydsort.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails the
+caller gets an exception (``YdsError``) carrying ``yds_last_error()``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libydsort.so")
+
+
+class YdsError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_SZ = C.c_size_t
+_I64 = C.c_int64
+
+# name -> (restype, argtypes); mirrors include/ydsort.h one to one
+SIGNATURES = {
+    "yds_init": (_I, [_I]),
+    "yds_last_error": (C.c_char_p, []),
+    "yds_device_count": (_I, []),
+    "yds_build_info": (C.c_char_p, []),
+    "yds_dev_alloc": (_P, [_SZ]),
+    "yds_dev_free": (_I, [_P]),
+    "yds_memcpy_h2d": (_I, [_P, _P, _SZ]),
+    "yds_memcpy_d2h": (_I, [_P, _P, _SZ]),
+    "yds_device_sync": (_I, []),
+    "yds_darknet_create": (_P, [C.c_char_p, _I, _I, _I]),
+    "yds_darknet_destroy": (None, [_P]),
+    "yds_darknet_load_weights": (_I, [_P, _P, _SZ, _I]),
+    "yds_darknet_num_boxes": (_I, [_P]),
+    "yds_darknet_num_attrs": (_I, [_P]),
+    "yds_darknet_num_layers": (_I, [_P]),
+    "yds_darknet_layer_shape": (_I, [_P, _I, _P, _P, _P]),
+    "yds_darknet_conv_flops": (_I64, [_P]),
+    "yds_darknet_forward_f32": (_I, [_P, _P, _I, _P]),
+    "yds_darknet_forward_u8": (_I, [_P, _P, _I, _I, _I, _P]),
+    "yds_darknet_forward_u8_dev": (_I, [_P, _P, _I, _I, _I]),
+    "yds_darknet_layer_output": (_I, [_P, _I, _I, _P]),
+    "yds_darknet_get_input": (_I, [_P, _I, _P]),
+    "yds_darknet_set_injection": (_I, [_P, _I, _P, _I, _F]),
+    "yds_nms": (_I, [_P, _I, _F, _F, _I, _I, _P, _I, _P]),
+    "yds_nms_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),
+    "yds_reid_create": (_P, [_I]),
+    "yds_reid_destroy": (None, [_P]),
+    "yds_reid_load_tensor": (_I, [_P, C.c_char_p, _P, _P, _I]),
+    "yds_reid_finalize": (_I, [_P]),
+    "yds_reid_flops_per_crop": (_I64, []),
+    "yds_reid_embed": (_I, [_P, _P, _I, _I, _P, _I, _P]),
+    "yds_reid_embed_dev": (_I, [_P, _P, _I, _I, _P, _I, _P]),
+    "yds_reid_features_dev": (_P, [_P]),
+    "yds_reid_preprocess": (_I, [_P, _P, _I, _I, _P, _I, _P]),
+    "yds_reid_forward_f32": (_I, [_P, _P, _I, _P]),
+    "yds_tracker_create": (_P, [C.c_double, C.c_double, _I, _I, _I]),
+    "yds_tracker_destroy": (None, [_P]),
+    "yds_tracker_step": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P]),
+    "yds_tracker_step_dev": (_I, [_P, _P, _P, _P, _I, _P, _I, _P]),
+    "yds_tracker_num_tracks": (_I, [_P]),
+    "yds_tracker_get_state": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "yds_tracker_last_unmatched": (_I, [_P, _P, _I, _P, _P, _I, _P]),
+    "yds_lsap": (_I, [_P, _I, _I, _P, _P, _P]),
+    "yds_kalman_predict": (_I, [_P, _P, _I]),
+    "yds_kalman_update": (_I, [_P, _P, _P, _I]),
+    "yds_kalman_gating": (_I, [_P, _P, _I, _P, _I, _P]),
+    "yds_iou_cost": (_I, [_P, _I, _P, _I, _P]),
+    "yds_cosine_min_cost": (_I, [_P, _P, _I, _P, _I, _I, _P]),
+    "yds_pipeline_create": (_P, [_P, _P, _P, _F, _F, _P, _I]),
+    "yds_pipeline_destroy": (None, [_P]),
+    "yds_pipeline_step": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    "yds_pipeline_stage_us": (_I, [_P, _P]),
+    "yds_conv_timing": (_I, [_P, _I, _P, _P, _P]),
+}
+
+_lib = None
+MISSING = []
+
+
+def load():
+    """Load libydsort.so and declare every prototype.  Raises YdsError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YdsError(f"{LIB_PATH} not found: build it with `python -m yolo_deepsort_amd.build` "
+                       "(the product has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:       # stale .so: calling the symbol raises, tests assert MISSING == []
+            MISSING.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().yds_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise YdsError(last_error())
+
+
+def check_ptr(p):
+    if not p:
+        raise YdsError(last_error())
+    return p
+
+
+_initialised = {}
+
+
+def init(device=0):
+    """yds_init once per process/device; raises when no MI355X is visible."""
+    if _initialised.get(device):
+        return
+    check(load().yds_init(int(device)))
+    _initialised[device] = True
+
+
+def ptr(a):
+    """Data pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class DeviceBuffer:
+    """Raw HBM allocation owned by Python (frames kept resident for the bench)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = check_ptr(load().yds_dev_alloc(self.nbytes))
+
+    @classmethod
+    def from_array(cls, a):
+        a = np.ascontiguousarray(a)
+        buf = cls(a.nbytes)
+        check(load().yds_memcpy_h2d(buf.ptr, ptr(a), a.nbytes))
+        return buf
+
+    def offset(self, nbytes):
+        return C.c_void_p(self.ptr + int(nbytes))
+
+    def free(self):
+        if self.ptr:
+            load().yds_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

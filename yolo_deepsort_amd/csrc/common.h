@@ -1,0 +1,113 @@
+// Shared declarations for libydsort (host side + kernel launchers).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+namespace yds {
+
+// ---- error plumbing ---------------------------------------------------------------------
+void set_error(const std::string &msg);
+struct Error : std::runtime_error {
+    explicit Error(const std::string &m) : std::runtime_error(m) {}
+};
+[[noreturn]] void fail(const char *fmt, ...);
+
+#define YDS_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            ::yds::fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// Runs `body`, converts C++ exceptions into the C ABI's status code.
+#define YDS_API_BEGIN try {
+#define YDS_API_END                                                                            \
+    }                                                                                          \
+    catch (const std::exception &e) {                                                          \
+        ::yds::set_error(e.what());                                                            \
+        return -1;                                                                             \
+    }                                                                                          \
+    return 0;
+#define YDS_API_END_PTR                                                                        \
+    }                                                                                          \
+    catch (const std::exception &e) {                                                          \
+        ::yds::set_error(e.what());                                                            \
+        return nullptr;                                                                        \
+    }
+
+// ---- device buffer ------------------------------------------------------------------------
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        if (count == 0) return;
+        YDS_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count) { if (count > n) alloc(count); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void upload(const T *src, size_t count, hipStream_t s = nullptr) {
+        ensure(count);
+        if (count) YDS_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+};
+
+// ---- NHWC tensor view ----------------------------------------------------------------------
+// fp32, pixel-major: element (n,y,x,c) at p[((n*h + y)*w + x)*ld + c].  ld >= c lets a layer write
+// straight into a channel slice of a wider (concatenated) buffer.
+struct View {
+    float *p = nullptr;
+    int n = 0, h = 0, w = 0, c = 0, ld = 0;
+    size_t pixels() const { return (size_t)n * h * w; }
+};
+
+enum Act { ACT_LINEAR = 0, ACT_LEAKY = 1, ACT_MISH = 2, ACT_RELU = 3 };
+enum ResMode { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
+
+// Implicit-GEMM convolution, fused bias (folded BN) + activation (+ residual).
+// w: [cout][kpad] fp32, k index = (kh*ksize + kw)*cin + ci, rows zero padded to kpad (multiple of 32).
+struct ConvArgs {
+    View x, y;
+    const float *w = nullptr, *bias = nullptr;
+    View res;              // optional residual (same n,h,w,c as y)
+    int ksize = 1, stride = 1, pad = 0, kpad = 0;
+    int act = ACT_LINEAR, res_mode = RES_NONE;
+};
+void launch_conv(const ConvArgs &a, hipStream_t s);
+double conv_flops(const ConvArgs &a);
+
+// ---- simple layers (layers.hip) --------------------------------------------------------------
+void launch_maxpool(const View &x, const View &y, int k, int stride, int pad, bool zero_pad_br, hipStream_t s);
+void launch_upsample(const View &x, const View &y, int stride, hipStream_t s);
+void launch_copy(const View &x, const View &y, hipStream_t s);                 // y[..., :c] = x[..., :c]
+void launch_add(const View &a, const View &b, const View &y, hipStream_t s);
+void launch_nchw_to_nhwc(const float *src_nchw, const View &y, int c_src, hipStream_t s);   // pads channels with 0
+void launch_nhwc_to_nchw(const View &x, float *dst_nchw, hipStream_t s);
+// yolo decode: head NHWC [n,h,w,A*(5+C)] -> out[n, box_off + a*h*w + y*w + x, 5+C]
+void launch_yolo_decode(const View &head, float *out, int total_boxes, int box_off, int num_classes,
+                        const float *anchors_wh /*host, A pairs*/, int A, int img_h, int img_w, hipStream_t s);
+void launch_inject(const View &head, int image, const float *rows_dev, int n, int head_index, int num_classes,
+                   float logit, hipStream_t s);
+// stretch-resize uint8 HWC frames to NHWC4 fp32 in [0,1] (4th channel 0)
+void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s);
+// ReID: crop + resize to 64x128 + /255 + mean/std -> NHWC4
+void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyxy_dev, int D, const View &y,
+                        hipStream_t s);
+void launch_avgpool_l2norm(const View &x, float *out, hipStream_t s);         // [D,8,4,512] -> [D,512]
+
+}  // namespace yds

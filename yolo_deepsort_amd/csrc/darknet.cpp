@@ -1,0 +1,525 @@
+// Darknet detector engine: cfg -> static execution plan over NHWC buffers -> HIP kernels.
+//
+// Mirrors reference yolo3/models/models.py: create_modules :25-102 (layer semantics),
+// Darknet.forward :292-313 (graph walk), load_darknet_weights :315-366 (file layout) and
+// yolo3/utils/parse_config.py:1-19 (cfg syntax), but is planned once at create time:
+//   * every conv is one fused implicit-GEMM launch (BN folded into weights/bias at load time,
+//     activation and the following shortcut add in the epilogue);
+//   * single-source routes and grouped routes are views (no copy); multi-source routes make their
+//     producers write straight into channel slices of the concatenated buffer when possible;
+//   * every layer keeps its own buffer for batch_max images (288 GB of HBM: no reuse games).
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+#include <map>
+#include <sstream>
+
+namespace yds {
+
+// ------------------------------------------------------------------------------------------ cfg
+std::vector<CfgBlock> parse_cfg(const std::string &text) {
+    // parse_config.py:1-19: drop empty and '#' lines, strip, '[type]' opens a block, key=value otherwise
+    std::vector<CfgBlock> blocks;
+    std::istringstream in(text);
+    std::string line;
+    auto strip = [](std::string s) {
+        size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+        return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+    };
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        line = strip(line);
+        if (line.empty()) fail("cfg: whitespace-only line (the reference parser rejects it too)");
+        if (line[0] == '[') {
+            CfgBlock b;
+            b.type = strip(line.substr(1, line.size() - 2));
+            if (b.type == "convolutional") b.kv["batch_normalize"] = "0";
+            blocks.push_back(b);
+        } else {
+            size_t eq = line.find('=');
+            if (eq == std::string::npos || line.find('=', eq + 1) != std::string::npos) fail("cfg: bad line '%s'", line.c_str());
+            if (blocks.empty()) fail("cfg: key before first section");
+            blocks.back().kv[strip(line.substr(0, eq))] = strip(line.substr(eq + 1));
+        }
+    }
+    return blocks;
+}
+
+static int geti(const CfgBlock &b, const char *k) {
+    auto it = b.kv.find(k);
+    if (it == b.kv.end()) fail("cfg: [%s] lacks '%s'", b.type.c_str(), k);
+    return atoi(it->second.c_str());
+}
+static std::vector<int> get_list(const CfgBlock &b, const char *k) {
+    auto it = b.kv.find(k);
+    if (it == b.kv.end()) fail("cfg: [%s] lacks '%s'", b.type.c_str(), k);
+    std::vector<int> v;
+    std::stringstream ss(it->second);
+    std::string tok;
+    while (std::getline(ss, tok, ',')) v.push_back(atoi(tok.c_str()));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------ plan
+Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_max) : img_h(img_h), img_w(img_w), batch_max(batch_max) {
+    YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    auto blocks = parse_cfg(cfg_text);
+    if (blocks.empty() || blocks[0].type != "net") fail("cfg: first section must be [net]");
+    in_channels = geti(blocks[0], "channels");
+    if (in_channels > 4) fail("cfg: more than 4 input channels is not supported");
+    blocks.erase(blocks.begin());
+    const int L = (int)blocks.size();
+    layers.resize(L);
+    auto resolve = [&](int ref, int i) {
+        int j = ref < 0 ? i + ref : ref;
+        if (j < 0 || j >= i) fail("cfg: layer %d references layer %d", i, ref);
+        return j;
+    };
+    // ---- pass 1: shapes, operators, references
+    int pc = 4, ph = img_h, pw = img_w;   // previous layer's logical shape (input is channel-padded to 4)
+    int prev_c_logical = in_channels;
+    (void)prev_c_logical;
+    for (int i = 0; i < L; ++i) {
+        Layer &l = layers[i];
+        const CfgBlock &b = blocks[i];
+        l.type = b.type;
+        l.root = i;
+        if (b.type == "convolutional") {
+            l.bn = geti(b, "batch_normalize");
+            l.ksize = geti(b, "size");
+            l.stride = geti(b, "stride");
+            l.pad = (l.ksize - 1) / 2;                       // models.py:39, cfg 'pad' ignored
+            l.cin = pc;
+            l.cin_file = i == 0 ? in_channels : pc;
+            l.c = geti(b, "filters");
+            l.h = (ph + 2 * l.pad - l.ksize) / l.stride + 1;
+            l.w = (pw + 2 * l.pad - l.ksize) / l.stride + 1;
+            std::string act = b.kv.count("activation") ? b.kv.at("activation") : "linear";
+            l.act = act == "leaky" ? ACT_LEAKY : act == "mish" ? ACT_MISH : ACT_LINEAR;   // models.py:53-56
+            l.src = i - 1;
+        } else if (b.type == "maxpool") {
+            l.ksize = geti(b, "size");
+            l.stride = geti(b, "stride");
+            l.c = pc;
+            if (l.ksize == 2 && l.stride == 1) {             // models.py:61-63 ZeroPad2d((0,1,0,1)) + MaxPool2d(2,1,pad 0)
+                l.zero_br = true;
+                l.pad = 0;
+                l.h = ph;
+                l.w = pw;
+            } else {
+                l.pad = (l.ksize - 1) / 2;
+                l.h = (ph + 2 * l.pad - l.ksize) / l.stride + 1;
+                l.w = (pw + 2 * l.pad - l.ksize) / l.stride + 1;
+            }
+            l.src = i - 1;
+        } else if (b.type == "upsample") {
+            l.stride = geti(b, "stride");
+            l.c = pc;
+            l.h = ph * l.stride;
+            l.w = pw * l.stride;
+            l.src = i - 1;
+        } else if (b.type == "route") {
+            for (int r : get_list(b, "layers")) l.refs.push_back(resolve(r, i));
+            l.c = 0;
+            for (int j : l.refs) {
+                l.c += layers[j].c;
+                if (layers[j].h != layers[l.refs[0]].h || layers[j].w != layers[l.refs[0]].w) fail("cfg: route %d joins different sizes", i);
+            }
+            l.h = layers[l.refs[0]].h;
+            l.w = layers[l.refs[0]].w;
+            if (b.kv.count("groups")) {
+                l.groups = geti(b, "groups");
+                l.group_id = geti(b, "group_id");
+                if (l.c % l.groups) fail("cfg: route %d groups do not divide channels", i);
+                l.c /= l.groups;
+            }
+        } else if (b.type == "shortcut") {
+            l.refs = {i - 1, resolve(geti(b, "from"), i)};
+            l.c = layers[l.refs[1]].c;
+            l.h = ph;
+            l.w = pw;
+            if (layers[l.refs[0]].c != l.c || layers[l.refs[1]].h != ph) fail("cfg: shortcut %d shape mismatch", i);
+        } else if (b.type == "yolo") {
+            auto mask = get_list(b, "mask");
+            auto an = get_list(b, "anchors");
+            for (int m : mask) {
+                if (2 * m + 1 >= (int)an.size()) fail("cfg: yolo %d mask out of range", i);
+                l.anchors.push_back((float)an[2 * m]);
+                l.anchors.push_back((float)an[2 * m + 1]);
+            }
+            l.classes = geti(b, "classes");
+            l.c = pc; l.h = ph; l.w = pw;
+            l.src = i - 1;
+            if (pc != (int)mask.size() * (l.classes + 5)) fail("cfg: yolo %d expects %d input channels, has %d", i, (int)mask.size() * (l.classes + 5), pc);
+            if (attrs == 0) attrs = l.classes + 5;
+            if (attrs != l.classes + 5) fail("cfg: yolo layers disagree on classes");
+            l.box_off = total_boxes;
+            total_boxes += (int)mask.size() * ph * pw;
+            yolo_layers.push_back(i);
+        } else {
+            fail("cfg: unsupported section [%s]", b.type.c_str());
+        }
+        pc = l.c; ph = l.h; pw = l.w;
+    }
+    if (yolo_layers.empty()) fail("cfg: no [yolo] layer");
+
+    // ---- pass 2: who reads whom (a conv can absorb the following shortcut only if nobody else
+    //      needs its pre-add output)
+    std::vector<int> readers(L, 0);
+    for (int i = 0; i < L; ++i) {
+        const Layer &l = layers[i];
+        if (l.src >= 0) readers[l.src]++;
+        for (int j : l.refs) readers[j]++;
+    }
+    for (int i = 1; i < L; ++i) {
+        Layer &l = layers[i];
+        if (l.type == "shortcut" && layers[i - 1].type == "convolutional" && readers[i - 1] == 1 && l.refs[1] != i - 1) {
+            layers[i - 1].fused_res = l.refs[1];
+            l.fused = true;
+            l.root = i - 1;          // view of the conv's (post-add) buffer
+            l.coff = 0;
+        }
+    }
+    // single-source routes are views
+    for (int i = 0; i < L; ++i) {
+        Layer &l = layers[i];
+        if (l.type == "route" && l.refs.size() == 1) {
+            const Layer &s = layers[l.refs[0]];
+            l.root = s.root;
+            l.coff = s.coff + (l.groups ? l.group_id * l.c : 0);
+            l.is_view = true;
+        }
+    }
+    // ---- pass 3: storage.  Producers own [batch_max, h, w, ld] buffers; a multi-source route owns the
+    //      concatenated buffer and redirects producers into its channel slices when they are free.
+    storage.resize(L);
+    auto is_producer = [&](int j) {
+        const Layer &s = layers[j];
+        return s.root == j && (s.type == "convolutional" || s.type == "maxpool" || s.type == "upsample" || (s.type == "shortcut" && !s.fused));
+    };
+    for (int i = 0; i < L; ++i) {
+        Layer &l = layers[i];
+        if (!(l.type == "route" && l.refs.size() > 1)) continue;
+        int ctot = 0;
+        for (int j : l.refs) ctot += layers[j].c;
+        if (ctot % 4) continue;                               // keep float4 alignment; falls back to a copy
+        storage[i].ld = ctot;
+        int off = 0;
+        for (int j : l.refs) {
+            const Layer &s = layers[j];
+            int r = s.root;
+            // redirect only whole-buffer sources that nobody redirected before
+            bool whole = r >= 0 && is_producer(r) && s.coff == 0 && s.c == layers[r].c && !storage[r].redirected && off % 4 == 0;
+            if (whole) {
+                storage[r].redirected = true;
+                storage[r].into = i;
+                storage[r].coff = off;
+            } else {
+                l.copies.push_back({j, off});
+            }
+            off += s.c;
+        }
+        if (l.groups) fail("cfg: grouped multi-source routes are not supported");
+    }
+    size_t total_floats = 0;
+    for (int i = 0; i < L; ++i) {
+        Layer &l = layers[i];
+        bool owns = (is_producer(i) && !storage[i].redirected) || (l.type == "route" && l.refs.size() > 1);
+        if (!owns) continue;
+        if (storage[i].ld == 0) storage[i].ld = (l.c + 3) / 4 * 4;
+        size_t n = (size_t)batch_max * l.h * l.w * storage[i].ld;
+        storage[i].buf.alloc(n);
+        YDS_HIP(hipMemsetAsync(storage[i].buf.p, 0, n * sizeof(float), stream));
+        total_floats += n;
+    }
+    input.alloc((size_t)batch_max * img_h * img_w * 4);
+    out.alloc((size_t)batch_max * total_boxes * attrs);
+    stage_f32.alloc((size_t)batch_max * img_h * img_w * 4);
+    activation_bytes = total_floats * sizeof(float);
+    YDS_HIP(hipStreamSynchronize(stream));
+    inject_rows.resize(batch_max);
+    inject_n.assign(batch_max, 0);
+}
+
+Darknet::~Darknet() {
+    if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+View Darknet::view(int i, int batch) const {
+    const Layer &l = layers[i];
+    int r = l.root;
+    View v;
+    v.n = batch; v.h = l.h; v.w = l.w; v.c = l.c;
+    if (l.type == "route" && l.refs.size() > 1) {
+        v.p = storage[i].buf.p; v.ld = storage[i].ld;
+        return v;
+    }
+    const Storage &st = storage[r];
+    if (st.redirected) {
+        const Storage &dst = storage[st.into];
+        v.p = dst.buf.p + st.coff + l.coff;
+        v.ld = dst.ld;
+    } else {
+        v.p = st.buf.p + l.coff;
+        v.ld = st.ld;
+    }
+    return v;
+}
+
+View Darknet::input_view(int batch) const {
+    View v;
+    v.p = input.p; v.n = batch; v.h = img_h; v.w = img_w; v.c = 4; v.ld = 4;
+    return v;
+}
+
+// --------------------------------------------------------------------------------------- weights
+size_t Darknet::weight_floats() const {
+    size_t n = 0;
+    for (const Layer &l : layers)
+        if (l.type == "convolutional") n += (size_t)(l.bn ? 4 : 1) * l.c + (size_t)l.c * l.cin_file * l.ksize * l.ksize;
+    return n;
+}
+
+void Darknet::load_weights(const void *blob, size_t nbytes, int cutoff) {
+    // models.py:315-366: 5 x int32 header, then per conv: [beta, gamma, mean, var] | [bias], then W[cout][cin][k][k]
+    if (nbytes < 20) fail("weights: blob shorter than the 20-byte header");
+    const float *w = reinterpret_cast<const float *>(static_cast<const char *>(blob) + 20);
+    size_t avail = (nbytes - 20) / 4, ptr = 0;
+    memcpy(header, blob, 20);
+    for (int i = 0; i < (int)layers.size(); ++i) {
+        if (cutoff >= 0 && i == cutoff) break;
+        Layer &l = layers[i];
+        if (l.type != "convolutional") continue;
+        const int co = l.c, ci = l.cin_file, k = l.ksize;
+        size_t need = (size_t)(l.bn ? 4 : 1) * co + (size_t)co * ci * k * k;
+        if (ptr + need > avail) fail("weights: file too short at layer %d (need %zu more floats, have %zu)", i, need, avail - ptr);
+        std::vector<double> scale(co, 1.0);
+        std::vector<float> bias(co);
+        if (l.bn) {
+            const float *beta = w + ptr, *gamma = beta + co, *mean = gamma + co, *var = mean + co;
+            ptr += 4 * (size_t)co;
+            for (int o = 0; o < co; ++o) {
+                scale[o] = (double)gamma[o] / sqrt((double)var[o] + 1e-5);      // BatchNorm2d eps=1e-5, models.py:52
+                bias[o] = (float)((double)beta[o] - (double)mean[o] * scale[o]);
+            }
+        } else {
+            for (int o = 0; o < co; ++o) bias[o] = w[ptr + o];
+            ptr += co;
+        }
+        const int cin_p = l.cin;                             // channel-padded input (3 -> 4 for the image)
+        const int K = k * k * cin_p;
+        l.kpad = (K + 31) / 32 * 32;
+        std::vector<float> packed((size_t)co * l.kpad, 0.f);
+        const float *src = w + ptr;
+        for (int o = 0; o < co; ++o)
+            for (int c = 0; c < ci; ++c)
+                for (int kh = 0; kh < k; ++kh)
+                    for (int kw = 0; kw < k; ++kw)
+                        packed[(size_t)o * l.kpad + (kh * k + kw) * cin_p + c] =
+                            (float)((double)src[(((size_t)o * ci + c) * k + kh) * k + kw] * scale[o]);
+        ptr += (size_t)co * ci * k * k;
+        l.wt.upload(packed.data(), packed.size(), stream);
+        l.bias.upload(bias.data(), bias.size(), stream);
+        YDS_HIP(hipStreamSynchronize(stream));
+        l.loaded = true;
+    }
+    weights_loaded = true;
+}
+
+// --------------------------------------------------------------------------------------- forward
+void Darknet::run_graph(int batch) {
+    if (batch < 1 || batch > batch_max) fail("forward: batch %d outside [1,%d]", batch, batch_max);
+    for (int i = 0; i < (int)layers.size(); ++i) {
+        Layer &l = layers[i];
+        if (l.type == "convolutional") {
+            if (!l.loaded) fail("forward: layer %d has no weights (call load_darknet_weights)", i);
+            ConvArgs a;
+            a.x = l.src < 0 ? input_view(batch) : view(l.src, batch);
+            a.y = view(i, batch);
+            a.w = l.wt.p; a.bias = l.bias.p;
+            a.ksize = l.ksize; a.stride = l.stride; a.pad = l.pad; a.kpad = l.kpad;
+            a.act = l.act;
+            if (l.fused_res >= 0) { a.res = view(l.fused_res, batch); a.res_mode = RES_AFTER_ACT; }
+            if (time_convs) YDS_HIP(hipEventRecord(ev0, stream));
+            launch_conv(a, stream);
+            if (time_convs) {
+                YDS_HIP(hipEventRecord(ev1, stream));
+                YDS_HIP(hipEventSynchronize(ev1));
+                float ms = 0;
+                YDS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+                conv_us += ms * 1e3;
+                conv_launches++;
+                conv_flops_acc += conv_flops(a);
+            }
+        } else if (l.type == "maxpool") {
+            launch_maxpool(view(l.src, batch), view(i, batch), l.ksize, l.stride, l.pad, l.zero_br, stream);
+        } else if (l.type == "upsample") {
+            launch_upsample(view(l.src, batch), view(i, batch), l.stride, stream);
+        } else if (l.type == "route") {
+            if (l.refs.size() > 1) {
+                View dst = view(i, batch);
+                for (auto &cp : l.copies) {
+                    View d = dst;
+                    d.p += cp.second;
+                    launch_copy(view(cp.first, batch), d, stream);
+                }
+            }
+        } else if (l.type == "shortcut") {
+            if (!l.fused) launch_add(view(l.refs[0], batch), view(l.refs[1], batch), view(i, batch), stream);
+        } else if (l.type == "yolo") {
+            View head = view(l.src, batch);
+            int hidx = 0;
+            for (int y : yolo_layers) { if (y == i) break; ++hidx; }
+            for (int b = 0; b < batch; ++b)
+                if (inject_active) launch_inject(head, b, inject_rows[b].p, inject_n[b], hidx, l.classes, inject_logit, stream);
+            launch_yolo_decode(head, out.p, total_boxes, l.box_off, l.classes, l.anchors.data(), (int)l.anchors.size() / 2, img_h, img_w, stream);
+        }
+    }
+}
+
+void Darknet::forward_f32_host(const float *nchw, int batch, float *out_host) {
+    size_t n = (size_t)batch * in_channels * img_h * img_w;
+    YDS_HIP(hipMemcpyAsync(stage_f32.p, nchw, n * sizeof(float), hipMemcpyHostToDevice, stream));
+    launch_nchw_to_nhwc(stage_f32.p, input_view(batch), in_channels, stream);
+    run_graph(batch);
+    if (out_host) YDS_HIP(hipMemcpyAsync(out_host, out.p, (size_t)batch * total_boxes * attrs * sizeof(float), hipMemcpyDeviceToHost, stream));
+    YDS_HIP(hipStreamSynchronize(stream));
+}
+
+void Darknet::forward_u8_dev(const uint8_t *frames_dev, int h, int w, int batch) {
+    if (in_channels != 3) fail("forward_u8: network expects %d channels", in_channels);
+    if (batch < 1 || batch > batch_max) fail("forward: batch %d outside [1,%d]", batch, batch_max);
+    launch_resize_u8(frames_dev, batch, h, w, input_view(batch), stream);
+    run_graph(batch);
+}
+
+void Darknet::forward_u8_host(const uint8_t *frames, int h, int w, int batch, float *out_host) {
+    size_t n = (size_t)batch * h * w * 3;
+    stage_u8.ensure(n);
+    YDS_HIP(hipMemcpyAsync(stage_u8.p, frames, n, hipMemcpyHostToDevice, stream));
+    forward_u8_dev(stage_u8.p, h, w, batch);
+    if (out_host) YDS_HIP(hipMemcpyAsync(out_host, out.p, (size_t)batch * total_boxes * attrs * sizeof(float), hipMemcpyDeviceToHost, stream));
+    YDS_HIP(hipStreamSynchronize(stream));
+}
+
+void Darknet::layer_output_host(int i, int batch, float *nchw) {
+    if (i < 0 || i >= (int)layers.size()) fail("layer_output: no layer %d", i);
+    const Layer &l = layers[i];
+    if (l.type == "yolo") fail("layer_output: yolo layers are read through the forward output");
+    if (l.fused_res >= 0) fail("layer_output: layer %d is fused with the following shortcut", i);
+    View v = view(i, batch);
+    DevBuf<float> tmp(v.pixels() * v.c);
+    launch_nhwc_to_nchw(v, tmp.p, stream);
+    YDS_HIP(hipMemcpyAsync(nchw, tmp.p, tmp.n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    YDS_HIP(hipStreamSynchronize(stream));
+}
+
+void Darknet::get_input_host(int batch, float *nchw) {
+    View v = input_view(batch);
+    v.c = in_channels;
+    DevBuf<float> tmp(v.pixels() * v.c);
+    launch_nhwc_to_nchw(v, tmp.p, stream);
+    YDS_HIP(hipMemcpyAsync(nchw, tmp.p, tmp.n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    YDS_HIP(hipStreamSynchronize(stream));
+}
+
+void Darknet::set_injection(int image, const float *rows, int n, float logit) {
+    if (image < 0 || image >= batch_max) fail("inject: image %d outside batch", image);
+    inject_n[image] = n;
+    if (n > 0) inject_rows[image].upload(rows, (size_t)n * 9, stream);
+    YDS_HIP(hipStreamSynchronize(stream));
+    inject_logit = logit;
+    inject_active = false;
+    for (int b = 0; b < batch_max; ++b) inject_active |= inject_n[b] > 0;
+}
+
+int64_t Darknet::flops_per_image() const {
+    int64_t f = 0;
+    for (const Layer &l : layers)
+        if (l.type == "convolutional") f += 2ll * l.h * l.w * l.c * l.ksize * l.ksize * l.cin_file;
+    return f;
+}
+
+void Darknet::enable_conv_timing(bool on) {
+    if (on && !ev0) { YDS_HIP(hipEventCreate(&ev0)); YDS_HIP(hipEventCreate(&ev1)); }
+    time_convs = on;
+}
+
+}  // namespace yds
+
+// ============================================================================================ C ABI
+using yds::Darknet;
+
+extern "C" {
+
+yds_net *yds_darknet_create(const char *cfg_text, int img_h, int img_w, int batch_max) {
+    YDS_API_BEGIN
+    if (!cfg_text) yds::fail("cfg_text is NULL");
+    if (img_h <= 0 || img_w <= 0 || batch_max <= 0) yds::fail("bad geometry %dx%d batch %d", img_h, img_w, batch_max);
+    auto *n = new yds_net{new Darknet(cfg_text, img_h, img_w, batch_max)};
+    return n;
+    YDS_API_END_PTR
+}
+void yds_darknet_destroy(yds_net *n) {
+    if (n) { delete n->d; delete n; }
+}
+int yds_darknet_load_weights(yds_net *n, const void *blob, size_t nbytes, int cutoff) {
+    YDS_API_BEGIN
+    n->d->load_weights(blob, nbytes, cutoff);
+    YDS_API_END
+}
+int yds_darknet_num_boxes(const yds_net *n) { return n->d->total_boxes; }
+int yds_darknet_num_attrs(const yds_net *n) { return n->d->attrs; }
+int yds_darknet_num_layers(const yds_net *n) { return (int)n->d->layers.size(); }
+int yds_darknet_layer_shape(const yds_net *n, int layer, int *c, int *h, int *w) {
+    YDS_API_BEGIN
+    if (layer < 0 || layer >= (int)n->d->layers.size()) yds::fail("no layer %d", layer);
+    const auto &l = n->d->layers[layer];
+    *c = l.c; *h = l.h; *w = l.w;
+    YDS_API_END
+}
+int64_t yds_darknet_conv_flops(const yds_net *n) { return n->d->flops_per_image(); }
+int yds_darknet_forward_f32(yds_net *n, const float *nchw_host, int batch, float *out_host) {
+    YDS_API_BEGIN
+    n->d->forward_f32_host(nchw_host, batch, out_host);
+    YDS_API_END
+}
+int yds_darknet_forward_u8(yds_net *n, const uint8_t *rgb, int h, int w, int batch, float *out_host) {
+    YDS_API_BEGIN
+    n->d->forward_u8_host(rgb, h, w, batch, out_host);
+    YDS_API_END
+}
+int yds_darknet_forward_u8_dev(yds_net *n, const uint8_t *rgb_dev, int h, int w, int batch) {
+    YDS_API_BEGIN
+    n->d->forward_u8_dev(rgb_dev, h, w, batch);
+    YDS_API_END
+}
+int yds_darknet_layer_output(yds_net *n, int layer, int batch, float *nchw_host) {
+    YDS_API_BEGIN
+    n->d->layer_output_host(layer, batch, nchw_host);
+    YDS_API_END
+}
+int yds_darknet_get_input(yds_net *n, int batch, float *nchw_host) {
+    YDS_API_BEGIN
+    n->d->get_input_host(batch, nchw_host);
+    YDS_API_END
+}
+int yds_darknet_set_injection(yds_net *n, int image, const float *rows, int cnt, float logit) {
+    YDS_API_BEGIN
+    n->d->set_injection(image, rows, cnt, logit);
+    YDS_API_END
+}
+int yds_conv_timing(yds_net *n, int reset, double *total_us, int64_t *launches, double *flops) {
+    YDS_API_BEGIN
+    Darknet *d = n->d;
+    if (total_us) *total_us = d->conv_us;
+    if (launches) *launches = d->conv_launches;
+    if (flops) *flops = d->conv_flops_acc;
+    if (reset == 1) { d->conv_us = 0; d->conv_launches = 0; d->conv_flops_acc = 0; d->enable_conv_timing(true); }
+    if (reset == 2) d->enable_conv_timing(false);
+    YDS_API_END
+}
+
+}  // extern "C"

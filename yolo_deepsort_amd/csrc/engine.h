@@ -1,0 +1,156 @@
+// Host-side engine classes of libydsort (detector, ReID, tracker, pipeline).
+#pragma once
+#include "common.h"
+
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace yds {
+
+struct CfgBlock {
+    std::string type;
+    std::map<std::string, std::string> kv;
+};
+std::vector<CfgBlock> parse_cfg(const std::string &text);
+
+struct Layer {
+    std::string type;
+    int c = 0, h = 0, w = 0;              // logical output shape
+    int root = -1, coff = 0;              // storage owner + channel offset (views)
+    bool is_view = false;
+    int src = -1;                         // single data input (conv/pool/upsample/yolo)
+    std::vector<int> refs;                // route sources / shortcut operands
+    std::vector<std::pair<int, int>> copies;   // (source layer, channel offset) needing a copy kernel
+    // conv
+    int bn = 0, ksize = 1, stride = 1, pad = 0, cin = 0, cin_file = 0, kpad = 0, act = ACT_LINEAR;
+    int fused_res = -1;                   // residual layer absorbed from the following shortcut
+    bool loaded = false;
+    DevBuf<float> wt, bias;
+    // shortcut / route / pool
+    bool fused = false, zero_br = false;
+    int groups = 0, group_id = 0;
+    // yolo
+    std::vector<float> anchors;
+    int classes = 0, box_off = 0;
+};
+
+struct Storage {
+    DevBuf<float> buf;
+    int ld = 0;
+    bool redirected = false;              // producer writes into a slice of storage[into]
+    int into = -1, coff = 0;
+};
+
+class Darknet {
+public:
+    Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_max);
+    ~Darknet();
+    void load_weights(const void *blob, size_t nbytes, int cutoff);
+    void forward_f32_host(const float *nchw, int batch, float *out_host);
+    void forward_u8_host(const uint8_t *frames, int h, int w, int batch, float *out_host);
+    void forward_u8_dev(const uint8_t *frames_dev, int h, int w, int batch);
+    void forward_resized(int batch) { run_graph(batch); }      // input buffer already filled
+    void layer_output_host(int layer, int batch, float *nchw);
+    void get_input_host(int batch, float *nchw);
+    void set_injection(int image, const float *rows, int n, float logit);
+    void enable_conv_timing(bool on);
+    int64_t flops_per_image() const;
+    size_t weight_floats() const;
+    View view(int layer, int batch) const;
+    View input_view(int batch) const;
+
+    int img_h, img_w, batch_max, in_channels = 3;
+    int total_boxes = 0, attrs = 0;
+    std::vector<Layer> layers;
+    std::vector<Storage> storage;
+    std::vector<int> yolo_layers;
+    DevBuf<float> input, out, stage_f32;
+    DevBuf<uint8_t> stage_u8;
+    hipStream_t stream = nullptr;
+    int32_t header[5] = {0, 0, 0, 0, 0};
+    bool weights_loaded = false;
+    size_t activation_bytes = 0;
+    // bench-only logit injection
+    std::vector<DevBuf<float>> inject_rows;
+    std::vector<int> inject_n;
+    bool inject_active = false;
+    float inject_logit = 6.f;
+    // conv timing (HIP events on this stream)
+    bool time_convs = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double conv_us = 0, conv_flops_acc = 0;
+    int64_t conv_launches = 0;
+
+private:
+    void run_graph(int batch);
+};
+
+// --------------------------------------------------------------------------------------------- NMS
+// Device multi-label NMS over decoded predictions [n_boxes, attrs] (nms.hip).
+class NmsWorkspace {
+public:
+    explicit NmsWorkspace(int max_candidates = 16384);
+    // returns number of rows written to out6_host (<= cap); rows sorted by score, boxes in model pixels
+    // scaled by (sx, sy) when scale is requested (resize_boxes).
+    int run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
+            float *out6_host, int cap, hipStream_t s);
+    int max_cand;
+    DevBuf<float> cand;          // [max_cand, 6]   x1,y1,x2,y2,score,cls in candidate order
+    DevBuf<float> sorted;        // [max_cand, 6]   score order
+    DevBuf<int> counts;          // [0] n candidates, [1] n kept
+    DevBuf<int> box_count;       // per box candidate count / offsets
+    DevBuf<unsigned long long> mask;   // [max_cand, max_cand/64] suppression bits
+    DevBuf<float> kept;          // [300, 6]
+    DevBuf<int> order;
+};
+
+// --------------------------------------------------------------------------------------------- ReID
+class ReidNet {
+public:
+    explicit ReidNet(int max_crops);
+    ~ReidNet();
+    void load_tensor(const std::string &name, const float *data, const int64_t *shape, int ndim);
+    void finalize();
+    void embed_dev(const uint8_t *frame_dev, int h, int w, const float *tlwh_host, int D, float *out_host);
+    void embed_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *out_host);
+    void preprocess_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *nchw_host);
+    void forward_f32_host(const float *nchw, int D, float *out_host);
+    void forward(int D);                     // input already in `in` (NHWC4)
+    static int64_t flops_per_crop();
+
+    struct ConvW {
+        int cin = 0, cin_file = 0, cout = 0, k = 0, stride = 1, pad = 0, kpad = 0;
+        DevBuf<float> wt, bias;
+    };
+    int max_crops;
+    std::map<std::string, std::vector<float>> raw;
+    std::map<std::string, std::vector<int64_t>> raw_shape;
+    bool ready = false;
+    std::vector<ConvW> convs;                // in execution order
+    std::vector<DevBuf<float>> bufs;
+    DevBuf<float> in, feat, stage_f32;
+    DevBuf<uint8_t> stage_u8;
+    DevBuf<int> boxes_dev;
+    hipStream_t stream = nullptr;
+    double conv_flops_last = 0;
+};
+
+// --------------------------------------------------------------------------------------------- tracker
+// Implemented in tracker.hip; the pipeline drives it through this interface.
+struct TrackerIface {
+    virtual ~TrackerIface() {}
+    // feats: [D,512] on device when feats_on_device, else host.  Returns rows written to out6 (int32 [m,6]).
+    virtual int step(const float *tlwh_host, const float *feats, bool feats_on_device, const float *payload_host, int D,
+                     int32_t *out6_host, int cap) = 0;
+    virtual int num_tracks() const = 0;
+};
+
+}  // namespace yds
+
+// C handles (shared by the translation units that implement the ABI)
+struct yds_net { yds::Darknet *d; };
+struct yds_reid { yds::ReidNet *r; };
+struct yds_trk { yds::TrackerIface *t; };

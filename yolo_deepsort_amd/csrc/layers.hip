@@ -1,0 +1,357 @@
+// HBM-bound layers of the detector / ReID graphs, NHWC fp32 with a per-pixel stride (ld) so that
+// producers can write straight into channel slices of concatenated buffers.
+//   maxpool  <- nn.MaxPool2d (+ ZeroPad2d for size=2,stride=1)   yolo3/models/models.py:58-64
+//   upsample <- UpsampleExpand (nearest)                           models.py:118-133
+//   copy     <- torch.cat / chunk of route layers                  models.py:300-303
+//   add      <- shortcut                                           models.py:304-306
+//   yolo     <- YOLOLayer.forward inference branch                 models.py:185-224
+//   resize   <- cv2.resize(INTER_LINEAR) + /255                    yolo3/detect/img_detect.py:70-72
+//   crop     <- frame[y1:y2,x1:x2] + cv2.resize + mean/std         deep_sort/deep_sort.py:138-141,
+//                                                                  deep_sort/deep/feature_extractor.py:34-51
+//   avgpool  <- AvgPool2d((8,4)) + x/||x||                         deep_sort/deep/model.py:70,88-91
+// All kernels are one-element(-vector)-per-thread streaming kernels with 16-byte accesses where the
+// layout allows; grids are capped and grid-strided.
+#include "common.h"
+
+namespace yds {
+
+static inline int grid_for(size_t work, int block = 256) {
+    size_t g = (work + block - 1) / block;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------ maxpool
+__global__ void maxpool_kernel(const float *x, float *y, int N, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
+                               int k, int stride, int pad, int zero_br) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c4 = idx % C4;
+        size_t pix = idx / C4;
+        int ox = pix % Wo;
+        size_t t = pix / Wo;
+        int oy = t % Ho;
+        int n = t / Ho;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int dy = 0; dy < k; ++dy) {
+            int iy = oy * stride - pad + dy;
+            for (int dx = 0; dx < k; ++dx) {
+                int ix = ox * stride - pad + dx;
+                float4 v;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ldx + c4 * 4);
+                else if (zero_br)
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                else
+                    continue;
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4 *>(y + pix * ldy + c4 * 4) = m;
+    }
+}
+
+void launch_maxpool(const View &x, const View &y, int k, int stride, int pad, bool zero_pad_br, hipStream_t s) {
+    if (x.c % 4 || x.ld % 4 || y.ld % 4) fail("maxpool: channels must be a multiple of 4");
+    size_t total = y.pixels() * (x.c / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, x.p, y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w,
+                       y.ld, k, stride, pad, zero_pad_br ? 1 : 0);
+    YDS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------ upsample
+__global__ void upsample_kernel(const float *x, float *y, int N, int H, int W, int C, int ldx, int ldy, int s) {
+    const int C4 = C >> 2, Ho = H * s, Wo = W * s;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c4 = idx % C4;
+        size_t pix = idx / C4;
+        int ox = pix % Wo;
+        size_t t = pix / Wo;
+        int oy = t % Ho;
+        int n = t / Ho;
+        *reinterpret_cast<float4 *>(y + pix * ldy + c4 * 4) =
+            *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + oy / s) * W + ox / s) * ldx + c4 * 4);
+    }
+}
+
+void launch_upsample(const View &x, const View &y, int stride, hipStream_t s) {
+    if (x.c % 4 || x.ld % 4 || y.ld % 4) fail("upsample: channels must be a multiple of 4");
+    size_t total = y.pixels() * (x.c / 4);
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x.p, y.p, x.n, x.h, x.w, x.c, x.ld, y.ld, stride);
+    YDS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------ copy / add
+__global__ void copy_kernel(const float *x, float *y, size_t pixels, int C, int ldx, int ldy) {
+    const int C4 = C >> 2;
+    const size_t total = pixels * C4;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c4 = idx % C4;
+        size_t pix = idx / C4;
+        *reinterpret_cast<float4 *>(y + pix * ldy + c4 * 4) = *reinterpret_cast<const float4 *>(x + pix * ldx + c4 * 4);
+    }
+}
+__global__ void copy_scalar_kernel(const float *x, float *y, size_t pixels, int C, int ldx, int ldy) {
+    const size_t total = pixels * C;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c = idx % C;
+        size_t pix = idx / C;
+        y[pix * ldy + c] = x[pix * ldx + c];
+    }
+}
+
+void launch_copy(const View &x, const View &y, hipStream_t s) {
+    bool vec = !(x.c % 4 || x.ld % 4 || y.ld % 4 || ((uintptr_t)x.p & 15) || ((uintptr_t)y.p & 15));
+    if (vec)
+        hipLaunchKernelGGL(copy_kernel, dim3(grid_for(x.pixels() * (x.c / 4))), dim3(256), 0, s, x.p, y.p, x.pixels(), x.c, x.ld, y.ld);
+    else
+        hipLaunchKernelGGL(copy_scalar_kernel, dim3(grid_for(x.pixels() * x.c)), dim3(256), 0, s, x.p, y.p, x.pixels(), x.c, x.ld, y.ld);
+    YDS_HIP(hipGetLastError());
+}
+
+__global__ void add_kernel(const float *a, const float *b, float *y, size_t pixels, int C, int lda, int ldb, int ldy) {
+    const size_t total = pixels * C;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c = idx % C;
+        size_t pix = idx / C;
+        y[pix * ldy + c] = a[pix * lda + c] + b[pix * ldb + c];
+    }
+}
+
+void launch_add(const View &a, const View &b, const View &y, hipStream_t s) {
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(a.pixels() * a.c)), dim3(256), 0, s, a.p, b.p, y.p, a.pixels(), a.c, a.ld, b.ld, y.ld);
+    YDS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float *src, float *y, int N, int C, int H, int W, int ldy, int Cdst) {
+    const size_t total = (size_t)N * H * W * Cdst;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c = idx % Cdst;
+        size_t pix = idx / Cdst;
+        int xw = pix % W;
+        size_t t = pix / W;
+        int yh = t % H;
+        int n = t / H;
+        y[pix * ldy + c] = c < C ? src[((size_t)(n * C + c) * H + yh) * W + xw] : 0.f;
+    }
+}
+void launch_nchw_to_nhwc(const float *src_nchw, const View &y, int c_src, hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(y.pixels() * y.c)), dim3(256), 0, s, src_nchw, y.p, y.n, c_src, y.h, y.w, y.ld, y.c);
+    YDS_HIP(hipGetLastError());
+}
+
+__global__ void nhwc_to_nchw_kernel(const float *x, float *dst, int N, int C, int H, int W, int ldx) {
+    const size_t total = (size_t)N * C * H * W;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int xw = idx % W;
+        size_t t = idx / W;
+        int yh = t % H;
+        t /= H;
+        int c = t % C;
+        int n = t / C;
+        dst[idx] = x[((size_t)(n * H + yh) * W + xw) * ldx + c];
+    }
+}
+void launch_nhwc_to_nchw(const View &x, float *dst_nchw, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(x.pixels() * x.c)), dim3(256), 0, s, x.p, dst_nchw, x.n, x.c, x.h, x.w, x.ld);
+    YDS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------ yolo decode
+struct YoloParams {
+    float aw[8], ah[8];   // anchors / scale, fp32 like the reference's scaled_anchors
+    float s0, s1;         // (img_h / H, img_w / W); quirk: x uses s0, y uses s1 (models.py:169-172,216)
+};
+
+__global__ void yolo_decode_kernel(const float *head, float *out, int N, int H, int W, int ld, int A, int attrs, int total_boxes,
+                                   int box_off, YoloParams yp) {
+    const int HW = H * W;
+    const size_t per_img = (size_t)A * HW * attrs;
+    const size_t total = per_img * N;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int t = idx % attrs;
+        size_t b = idx / attrs;
+        int box = b % ((size_t)A * HW);
+        int n = b / ((size_t)A * HW);
+        int a = box / HW, cell = box - a * HW;
+        int gy = cell / W, gx = cell - gy * W;
+        float v = head[((size_t)(n * H + gy) * W + gx) * ld + a * attrs + t];
+        float r;
+        if (t == 0) r = __fmul_rn(__fadd_rn(1.f / (1.f + expf(-v)), (float)gx), yp.s0);
+        else if (t == 1) r = __fmul_rn(__fadd_rn(1.f / (1.f + expf(-v)), (float)gy), yp.s1);
+        else if (t == 2) r = __fmul_rn(__fmul_rn(expf(v), yp.aw[a]), yp.s0);
+        else if (t == 3) r = __fmul_rn(__fmul_rn(expf(v), yp.ah[a]), yp.s1);
+        else r = 1.f / (1.f + expf(-v));
+        out[((size_t)n * total_boxes + box_off + box) * attrs + t] = r;
+    }
+}
+
+void launch_yolo_decode(const View &head, float *out, int total_boxes, int box_off, int num_classes, const float *anchors_wh,
+                        int A, int img_h, int img_w, hipStream_t s) {
+    if (A > 8) fail("yolo: at most 8 anchors per head");
+    YoloParams yp;
+    yp.s0 = (float)((double)img_h / head.h);
+    yp.s1 = (float)((double)img_w / head.w);
+    for (int a = 0; a < A; ++a) {
+        yp.aw[a] = anchors_wh[2 * a] / yp.s0;
+        yp.ah[a] = anchors_wh[2 * a + 1] / yp.s1;
+    }
+    int attrs = num_classes + 5;
+    if (head.c != A * attrs) fail("yolo: head has %d channels, expected %d", head.c, A * attrs);
+    size_t total = (size_t)head.n * A * head.h * head.w * attrs;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, s, head.p, out, head.n, head.h, head.w, head.ld, A,
+                       attrs, total_boxes, box_off, yp);
+    YDS_HIP(hipGetLastError());
+}
+
+// bench-only logit injection: objectness := -logit everywhere, then scripted cells
+__global__ void inject_clear_kernel(float *head, int image, int H, int W, int ld, int A, int attrs, float logit) {
+    int total = H * W * A;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int a = idx % A, cell = idx / A;
+        head[((size_t)image * H * W + cell) * ld + a * attrs + 4] = -logit;
+    }
+}
+__global__ void inject_rows_kernel(float *head, int image, int H, int W, int ld, int attrs, const float *rows, int n, int head_index,
+                                   float logit) {
+    int r = blockIdx.x;
+    if (r >= n) return;
+    const float *row = rows + r * 9;
+    if ((int)row[0] != head_index) return;
+    int a = (int)row[1], gy = (int)row[2], gx = (int)row[3], cls = (int)row[8];
+    float *cell = head + ((size_t)(image * H + gy) * W + gx) * ld + a * attrs;
+    for (int t = threadIdx.x; t < attrs; t += blockDim.x) {
+        float v;
+        if (t < 4) v = row[4 + t];
+        else if (t == 4) v = logit;
+        else v = (t - 5 == cls) ? logit : -logit;
+        cell[t] = v;
+    }
+}
+void launch_inject(const View &head, int image, const float *rows_dev, int n, int head_index, int num_classes, float logit,
+                   hipStream_t s) {
+    int attrs = num_classes + 5, A = head.c / attrs;
+    hipLaunchKernelGGL(inject_clear_kernel, dim3(grid_for((size_t)head.h * head.w * A)), dim3(256), 0, s, head.p, image, head.h, head.w,
+                       head.ld, A, attrs, logit);
+    if (n > 0)
+        hipLaunchKernelGGL(inject_rows_kernel, dim3(n), dim3(128), 0, s, head.p, image, head.h, head.w, head.ld, attrs, rows_dev, n,
+                           head_index, logit);
+    YDS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------ bilinear u8
+// Spec (oracle/resize.py): half-pixel centres, clamped source index, fp32 lerp with every product and
+// sum rounded separately (no FMA), round-half-even to the uint8 grid.
+struct Tap { int i0, i1; float f; };
+__device__ __forceinline__ Tap axis_tap(int d, float scale, int src) {
+    float f = __fsub_rn(__fmul_rn(__fadd_rn((float)d, 0.5f), scale), 0.5f);
+    float fl = floorf(f);
+    Tap t;
+    t.i0 = (int)fl;
+    t.f = __fsub_rn(f, fl);
+    if (t.i0 < 0) { t.i0 = 0; t.f = 0.f; }
+    if (t.i0 >= src - 1) { t.i0 = src - 1; t.f = 0.f; }
+    t.i1 = min(t.i0 + 1, src - 1);
+    return t;
+}
+__device__ __forceinline__ float lerp2(float p00, float p01, float p10, float p11, float fx, float fy) {
+    float gx = __fsub_rn(1.f, fx), gy = __fsub_rn(1.f, fy);
+    float top = __fadd_rn(__fmul_rn(gx, p00), __fmul_rn(fx, p01));
+    float bot = __fadd_rn(__fmul_rn(gx, p10), __fmul_rn(fx, p11));
+    float v = __fadd_rn(__fmul_rn(gy, top), __fmul_rn(fy, bot));
+    return fminf(fmaxf(rintf(v), 0.f), 255.f);
+}
+
+__global__ void resize_u8_kernel(const uint8_t *frames, int N, int H, int W, float *y, int Ho, int Wo, int ldy) {
+    const float sx = __fdiv_rn((float)W, (float)Wo), sy = __fdiv_rn((float)H, (float)Ho);
+    const size_t total = (size_t)N * Ho * Wo;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int ox = idx % Wo;
+        size_t t = idx / Wo;
+        int oy = t % Ho;
+        int n = t / Ho;
+        Tap tx = axis_tap(ox, sx, W), ty = axis_tap(oy, sy, H);
+        const uint8_t *img = frames + (size_t)n * H * W * 3;
+        const uint8_t *r0 = img + (size_t)ty.i0 * W * 3, *r1 = img + (size_t)ty.i1 * W * 3;
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = lerp2(r0[tx.i0 * 3 + c], r0[tx.i1 * 3 + c], r1[tx.i0 * 3 + c], r1[tx.i1 * 3 + c], tx.f, ty.f);
+            o[c] = __fdiv_rn(v, 255.f);
+        }
+        o[3] = 0.f;
+        *reinterpret_cast<float4 *>(y + idx * ldy) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s) {
+    if (y.c != 4 || y.ld != 4) fail("resize: destination must be NHWC4");
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for((size_t)n * y.h * y.w)), dim3(256), 0, s, frames, n, h, w, y.p, y.h, y.w, y.ld);
+    YDS_HIP(hipGetLastError());
+}
+
+__global__ void crop_resize_kernel(const uint8_t *frame, int H, int W, const int *boxes, int D, float *y, int Ho, int Wo) {
+    const size_t total = (size_t)D * Ho * Wo;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int ox = idx % Wo;
+        size_t t = idx / Wo;
+        int oy = t % Ho;
+        int d = t / Ho;
+        int x1 = boxes[d * 4], y1 = boxes[d * 4 + 1], cw = boxes[d * 4 + 2] - x1, ch = boxes[d * 4 + 3] - y1;
+        Tap tx = axis_tap(ox, __fdiv_rn((float)cw, (float)Wo), cw), ty = axis_tap(oy, __fdiv_rn((float)ch, (float)Ho), ch);
+        const uint8_t *r0 = frame + ((size_t)(y1 + ty.i0) * W + x1) * 3, *r1 = frame + ((size_t)(y1 + ty.i1) * W + x1) * 3;
+        const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = lerp2(r0[tx.i0 * 3 + c], r0[tx.i1 * 3 + c], r1[tx.i0 * 3 + c], r1[tx.i1 * 3 + c], tx.f, ty.f);
+            o[c] = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), mean[c]), stdv[c]);
+        }
+        o[3] = 0.f;
+        *reinterpret_cast<float4 *>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyxy_dev, int D, const View &y, hipStream_t s) {
+    if (D == 0) return;
+    hipLaunchKernelGGL(crop_resize_kernel, dim3(grid_for((size_t)D * y.h * y.w)), dim3(256), 0, s, frame, h, w, boxes_xyxy_dev, D, y.p,
+                       y.h, y.w);
+    YDS_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------ ReID tail
+__global__ void avgpool_l2norm_kernel(const float *x, float *out, int P, int C, int ld) {
+    // one workgroup per crop; C == blockDim.x * 2
+    __shared__ float red[8];
+    const int d = blockIdx.x;
+    float v[2], ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int c = threadIdx.x + j * blockDim.x;
+        float sum = 0.f;
+        for (int p = 0; p < P; ++p) sum += x[((size_t)d * P + p) * ld + c];
+        v[j] = sum / (float)P;
+        ss += v[j] * v[j];
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+    float nrm = sqrtf(tot);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) out[(size_t)d * C + threadIdx.x + j * blockDim.x] = v[j] / nrm;
+}
+
+void launch_avgpool_l2norm(const View &x, float *out, hipStream_t s) {
+    if (x.n == 0) return;
+    if (x.c != 512) fail("avgpool: expected 512 channels");
+    hipLaunchKernelGGL(avgpool_l2norm_kernel, dim3(x.n), dim3(256), 0, s, x.p, out, x.h * x.w, x.c, x.ld);
+    YDS_HIP(hipGetLastError());
+}
+
+}  // namespace yds

@@ -1,0 +1,246 @@
+// Detector post-processing on device.
+//
+// soft_non_max_suppression (reference yolo3/utils/model_build.py:52-137; despite its name it is hard,
+// multi-label NMS) + resize_boxes (:12-19).  The greedy step is torchvision.ops.boxes.nms semantics
+// (third party; call site model_build.py:119): stable sort by score descending, area (x2-x1)*(y2-y1),
+// suppress j when inter/(a_i + a_j - inter) > thr with the threshold held as double.
+//
+// Pipeline (all sizes stay on device, one host sync at the end):
+//   count   one thread per box: obj > thr, number of classes with cls*obj > thr
+//   scan    exclusive prefix over boxes -> candidate slot of every (box, class) pair; this reproduces
+//           torch.nonzero's row-major order (box ascending, class ascending)
+//   emit    rows (x1,y1,x2,y2,score,cls), xywh -> xyxy as x -+ w/2
+//   rank    stable descending rank of every candidate (score desc, candidate index asc) and scatter
+//   mask    64-bit suppression words over class-offset boxes (box + cls*4096 in fp32, like the reference)
+//   sweep   one workgroup walks candidates in score order, keeps <= 300
+// Integer/index results are bit-exact against the oracle; the arithmetic is plain fp32 with explicit
+// rounding (no FMA contraction) so that threshold decisions match.
+#include "engine.h"
+
+namespace yds {
+
+constexpr int MAX_DET = 300;
+
+__global__ void nms_count_kernel(const float *pred, int n_boxes, int attrs, float thr, int *box_count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_boxes) return;
+    const float *p = pred + (size_t)i * attrs;
+    int cnt = 0;
+    float obj = p[4];
+    if (obj > thr) {
+        for (int j = 5; j < attrs; ++j) cnt += __fmul_rn(p[j], obj) > thr;
+    }
+    box_count[i] = cnt;
+}
+
+// single-workgroup exclusive scan, in place; total -> counts[0]
+__global__ void nms_scan_kernel(int *box_count, int n_boxes, int *counts) {
+    __shared__ int wave_sum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_boxes; base += blockDim.x) {
+        int i = base + tid;
+        int v = i < n_boxes ? box_count[i] : 0;
+        int incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_sum[w];
+        int c = carry;
+        if (i < n_boxes) box_count[i] = c + woff + incl - v;
+        __syncthreads();
+        if (tid == (int)blockDim.x - 1) carry = c + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) { counts[0] = carry; counts[1] = 0; }
+}
+
+__global__ void nms_emit_kernel(const float *pred, int n_boxes, int attrs, float thr, const int *box_off, int max_cand, float *cand) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_boxes) return;
+    const float *p = pred + (size_t)i * attrs;
+    float obj = p[4];
+    if (!(obj > thr)) return;
+    int slot = box_off[i];
+    float hw = __fdiv_rn(p[2], 2.f), hh = __fdiv_rn(p[3], 2.f);
+    float x1 = __fsub_rn(p[0], hw), y1 = __fsub_rn(p[1], hh), x2 = __fadd_rn(p[0], hw), y2 = __fadd_rn(p[1], hh);
+    for (int j = 5; j < attrs; ++j) {
+        float sc = __fmul_rn(p[j], obj);
+        if (sc > thr) {
+            if (slot < max_cand) {
+                float *r = cand + (size_t)slot * 6;
+                r[0] = x1; r[1] = y1; r[2] = x2; r[3] = y2; r[4] = sc; r[5] = (float)(j - 5);
+            }
+            ++slot;
+        }
+    }
+}
+
+__global__ void nms_rank_kernel(const float *cand, const int *counts, int max_cand, float *sorted) {
+    __shared__ float tile[256];
+    const int n = min(counts[0], max_cand);
+    for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+        int i = base + threadIdx.x;
+        float si = i < n ? cand[(size_t)i * 6 + 4] : 0.f;
+        int rank = 0;
+        for (int t0 = 0; t0 < n; t0 += 256) {
+            int j = t0 + threadIdx.x;
+            tile[threadIdx.x] = j < n ? cand[(size_t)j * 6 + 4] : -INFINITY;
+            __syncthreads();
+            int lim = min(256, n - t0);
+            for (int k = 0; k < lim; ++k) {
+                float sj = tile[k];
+                rank += (sj > si) || (sj == si && (t0 + k) < i);
+            }
+            __syncthreads();
+        }
+        if (i < n) {
+            const float *s = cand + (size_t)i * 6;
+            float *d = sorted + (size_t)rank * 6;
+            for (int k = 0; k < 6; ++k) d[k] = s[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void offset_box(const float *r, float b[4]) {
+    float c = __fmul_rn(r[5], 4096.f);       // model_build.py:117 class offset, fp32
+    b[0] = __fadd_rn(r[0], c); b[1] = __fadd_rn(r[1], c); b[2] = __fadd_rn(r[2], c); b[3] = __fadd_rn(r[3], c);
+}
+
+__global__ void nms_mask_kernel(const float *sorted, const int *counts, int max_cand, double thr, unsigned long long *mask, int words_ld) {
+    const int n = min(counts[0], max_cand);
+    const int words = (n + 63) / 64;
+    const long total = (long)n * words;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int i = idx / words, w = idx - (long)i * words;
+        unsigned long long bits = 0;
+        int j0 = w * 64;
+        if (j0 + 63 > i) {
+            float bi[4];
+            offset_box(sorted + (size_t)i * 6, bi);
+            float ai = __fmul_rn(__fsub_rn(bi[2], bi[0]), __fsub_rn(bi[3], bi[1]));
+            for (int b = 0; b < 64; ++b) {
+                int j = j0 + b;
+                if (j <= i || j >= n) continue;
+                float bj[4];
+                offset_box(sorted + (size_t)j * 6, bj);
+                float aj = __fmul_rn(__fsub_rn(bj[2], bj[0]), __fsub_rn(bj[3], bj[1]));
+                float xx1 = fmaxf(bi[0], bj[0]), yy1 = fmaxf(bi[1], bj[1]);
+                float xx2 = fminf(bi[2], bj[2]), yy2 = fminf(bi[3], bj[3]);
+                float ww = fmaxf(0.f, __fsub_rn(xx2, xx1)), hh = fmaxf(0.f, __fsub_rn(yy2, yy1));
+                float inter = __fmul_rn(ww, hh);
+                float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, aj), inter));
+                if ((double)ovr > thr) bits |= 1ull << b;
+            }
+        }
+        mask[(size_t)i * words_ld + w] = bits;
+    }
+}
+
+__global__ void nms_sweep_kernel(const float *sorted, const unsigned long long *mask, int words_ld, int *counts, int max_cand,
+                                 float sx, float sy, float *kept, int cap) {
+    extern __shared__ unsigned long long removed[];
+    __shared__ int n_keep;
+    const int n = min(counts[0], max_cand);
+    const int words = (n + 63) / 64;
+    for (int w = threadIdx.x; w < words; w += blockDim.x) removed[w] = 0;
+    if (threadIdx.x == 0) n_keep = 0;
+    __syncthreads();
+    const int lim = min(cap, MAX_DET);
+    for (int i = 0; i < n; ++i) {
+        bool alive = !((removed[i >> 6] >> (i & 63)) & 1ull);
+        int k = n_keep;
+        if (k >= lim) break;
+        __syncthreads();
+        if (alive) {
+            for (int w = threadIdx.x; w < words; w += blockDim.x) removed[w] |= mask[(size_t)i * words_ld + w];
+            if (threadIdx.x < 6) {
+                float v = sorted[(size_t)i * 6 + threadIdx.x];
+                if (threadIdx.x == 0 || threadIdx.x == 2) v = __fmul_rn(v, sx);     // resize_boxes :12-19
+                if (threadIdx.x == 1 || threadIdx.x == 3) v = __fmul_rn(v, sy);
+                kept[(size_t)k * 6 + threadIdx.x] = v;
+            }
+            if (threadIdx.x == 0) n_keep = k + 1;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) counts[1] = n_keep;
+}
+
+NmsWorkspace::NmsWorkspace(int max_candidates) : max_cand(max_candidates) {
+    cand.alloc((size_t)max_cand * 6);
+    sorted.alloc((size_t)max_cand * 6);
+    counts.alloc(4);
+    mask.alloc((size_t)max_cand * (max_cand / 64));
+    kept.alloc((size_t)MAX_DET * 6);
+}
+
+int NmsWorkspace::run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
+                      float *out6_host, int cap, hipStream_t s) {
+    if (attrs < 6) fail("nms: predictions need at least one class");
+    box_count.ensure(n_boxes);
+    const int nb = (n_boxes + 255) / 256;
+    hipLaunchKernelGGL(nms_count_kernel, dim3(nb), dim3(256), 0, s, pred_dev, n_boxes, attrs, conf_thres, box_count.p);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, s, box_count.p, n_boxes, counts.p);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(nb), dim3(256), 0, s, pred_dev, n_boxes, attrs, conf_thres, box_count.p, max_cand, cand.p);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(64), dim3(256), 0, s, cand.p, counts.p, max_cand, sorted.p);
+    const int words_ld = max_cand / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(512), dim3(256), 0, s, sorted.p, counts.p, max_cand, (double)iou_thres, mask.p, words_ld);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), words_ld * sizeof(unsigned long long), s, sorted.p, mask.p, words_ld, counts.p,
+                       max_cand, sx, sy, kept.p, cap);
+    YDS_HIP(hipGetLastError());
+    int h_counts[2] = {0, 0};
+    YDS_HIP(hipMemcpyAsync(h_counts, counts.p, sizeof h_counts, hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipStreamSynchronize(s));
+    if (h_counts[0] > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (raise conf_thres)", h_counts[0], max_cand);
+    int n = h_counts[1];
+    if (n > 0) {
+        YDS_HIP(hipMemcpyAsync(out6_host, kept.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+        YDS_HIP(hipStreamSynchronize(s));
+    }
+    return n;
+}
+
+}  // namespace yds
+
+// ============================================================================================ C ABI
+
+namespace {
+yds::NmsWorkspace &workspace() {
+    static thread_local std::unique_ptr<yds::NmsWorkspace> ws;
+    if (!ws) ws.reset(new yds::NmsWorkspace());
+    return *ws;
+}
+}  // namespace
+
+extern "C" {
+
+int yds_nms(yds_net *n, int image, float conf_thres, float iou_thres, int frame_h, int frame_w, float *out6_host, int cap, int *n_out) {
+    YDS_API_BEGIN
+    yds::Darknet *d = n->d;
+    if (image < 0 || image >= d->batch_max) yds::fail("nms: image %d outside batch", image);
+    // resize_boxes (model_build.py:12-19): python-double ratio rounded to fp32, fp32 multiply
+    float sx = frame_h > 0 ? (float)((double)frame_w / d->img_w) : 1.f;
+    float sy = frame_h > 0 ? (float)((double)frame_h / d->img_h) : 1.f;
+    const float *pred = d->out.p + (size_t)image * d->total_boxes * d->attrs;
+    *n_out = workspace().run(pred, d->total_boxes, d->attrs, conf_thres, iou_thres, sx, sy, out6_host, cap, d->stream);
+    YDS_API_END
+}
+
+int yds_nms_pred(const float *pred_host, int n_boxes, int attrs, float conf_thres, float iou_thres, float *out6_host, int cap, int *n_out) {
+    YDS_API_BEGIN
+    yds::DevBuf<float> pred;
+    pred.upload(pred_host, (size_t)n_boxes * attrs);
+    YDS_HIP(hipStreamSynchronize(nullptr));
+    *n_out = workspace().run(pred.p, n_boxes, attrs, conf_thres, iou_thres, 1.f, 1.f, out6_host, cap, nullptr);
+    YDS_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+// Runtime plumbing of libydsort: error reporting, device selection, raw HBM buffers.
+#include "common.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+namespace yds {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+void fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(buf);
+}
+
+}  // namespace yds
+
+extern "C" {
+
+const char *yds_last_error(void) { return yds::g_last_error.c_str(); }
+
+const char *yds_build_info(void) { return "libydsort 0.1 (HIP, gfx950, fp32 MFMA implicit-GEMM conv)"; }
+
+int yds_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int yds_init(int device_id) {
+    YDS_API_BEGIN
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) yds::fail("no HIP device visible (%s); libydsort has no CPU path", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) yds::fail("device %d outside [0,%d)", device_id, n);
+    YDS_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    YDS_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        yds::fail("device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    YDS_API_END
+}
+
+void *yds_dev_alloc(size_t nbytes) {
+    YDS_API_BEGIN
+    void *p = nullptr;
+    YDS_HIP(hipMalloc(&p, nbytes ? nbytes : 1));
+    return p;
+    YDS_API_END_PTR
+}
+
+int yds_dev_free(void *dev) {
+    YDS_API_BEGIN
+    if (dev) YDS_HIP(hipFree(dev));
+    YDS_API_END
+}
+
+int yds_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes) {
+    YDS_API_BEGIN
+    YDS_HIP(hipMemcpy(dst_dev, src_host, nbytes, hipMemcpyHostToDevice));
+    YDS_API_END
+}
+
+int yds_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes) {
+    YDS_API_BEGIN
+    YDS_HIP(hipMemcpy(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost));
+    YDS_API_END
+}
+
+int yds_device_sync(void) {
+    YDS_API_BEGIN
+    YDS_HIP(hipDeviceSynchronize());
+    YDS_API_END
+}
+
+}  // extern "C"

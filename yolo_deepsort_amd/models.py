@@ -1,0 +1,182 @@
+"""Drop-in ``Darknet`` (reference yolo3/models/models.py:277-394) backed by libydsort.
+
+Same constructor, attributes and call convention as the reference class; the graph
+is planned and executed by the HIP engine (csrc/darknet.cpp).  No torch autograd:
+this is an inference engine, ``parameters()`` exists only so that
+``ImageDetector`` can read a device off it (img_detect.py:47).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .loaders import parse_model_config
+
+
+def _to_numpy(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+class _Param:
+    """Minimal stand-in for a torch parameter: carries the device only."""
+
+    def __init__(self, device):
+        self.device = device
+
+
+class Darknet:
+    def __init__(self, config_path, img_size=416, batch_max=1, cfg_text=None):
+        _lib.init(0)
+        if cfg_text is None:
+            with open(config_path, "r") as f:
+                cfg_text = f.read()
+        self.cfg_text = cfg_text
+        defs = parse_model_config(config_path, text=cfg_text)
+        self.hyperparams = defs.pop(0)
+        self.module_defs = defs
+        self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        self.seen = 0
+        self.header_info = np.array([0, 0, 0, self.seen, 0], dtype=np.int32)
+        self.batch_max = int(batch_max)
+        self.device = "cuda:0"
+        self._half = False
+        self._h = None
+        self._create()
+
+    def _create(self):
+        lib = _lib.load()
+        if self._h:
+            lib.yds_darknet_destroy(self._h)
+        self._h = _lib.check_ptr(lib.yds_darknet_create(self.cfg_text.encode(), self.img_size[0], self.img_size[1],
+                                                        self.batch_max))
+        self.num_boxes = lib.yds_darknet_num_boxes(self._h)
+        self.num_attrs = lib.yds_darknet_num_attrs(self._h)
+        blob = getattr(self, "_weights_blob", None)
+        if blob is not None:
+            _lib.check(lib.yds_darknet_load_weights(self._h, blob, len(blob), self._cutoff))
+
+    def set_batch_max(self, batch_max):
+        if batch_max != self.batch_max:
+            self.batch_max = int(batch_max)
+            self._create()
+
+    # -- reference API -------------------------------------------------
+    def load_darknet_weights(self, weights_path, blob=None):
+        """models.py:315-366; ``blob`` lets callers pass the file content directly."""
+        if blob is None:
+            with open(weights_path, "rb") as f:
+                blob = f.read()
+        self.header_info = np.frombuffer(blob[:20], dtype=np.int32).copy()
+        self.seen = self.header_info[3]
+        self._cutoff = 75 if (weights_path and "darknet53.conv.74" in str(weights_path)) else -1
+        self._weights_blob = bytes(blob)
+        _lib.check(_lib.load().yds_darknet_load_weights(self._h, self._weights_blob, len(blob), self._cutoff))
+
+    def to(self, device):
+        self.device = str(device)
+        return self
+
+    def cuda(self):
+        return self.to("cuda:0")
+
+    def eval(self):
+        return self
+
+    def half(self):
+        # img_detect.py:49-50; the engine computes in fp32 (north_star tolerance), flag kept for API parity
+        self._half = True
+        return self
+
+    def parameters(self):
+        yield _Param(self.device)
+
+    def forward(self, x, targets=None):
+        if targets is not None:
+            raise NotImplementedError("training loss is out of scope (SURVEY 8a)")
+        xn = _to_numpy(x)
+        if xn.ndim != 4 or xn.shape[2:] != self.img_size:
+            raise ValueError(f"expected [B,C,{self.img_size[0]},{self.img_size[1]}], got {xn.shape}")
+        b = xn.shape[0]
+        if b > self.batch_max:
+            self.set_batch_max(b)
+        out = np.empty((b, self.num_boxes, self.num_attrs), np.float32)
+        _lib.check(_lib.load().yds_darknet_forward_f32(self._h, _lib.ptr(xn), b, _lib.ptr(out)))
+        return _wrap_like(x, out)
+
+    __call__ = forward
+
+    # -- engine extras ---------------------------------------------------
+    def forward_u8(self, frames, want_output=True):
+        """frames uint8 [B,H,W,3] (host) -> decoded predictions [B,N,5+C]."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim == 3:
+            frames = frames[None]
+        b, h, w, _ = frames.shape
+        if b > self.batch_max:
+            self.set_batch_max(b)
+        out = np.empty((b, self.num_boxes, self.num_attrs), np.float32) if want_output else None
+        _lib.check(_lib.load().yds_darknet_forward_u8(self._h, _lib.ptr(frames), h, w, b, _lib.ptr(out)))
+        return out
+
+    def nms(self, image, conf_thres, iou_thres, frame_hw=None, cap=300):
+        """soft_non_max_suppression (+ resize_boxes when frame_hw is given) on the last forward."""
+        out = np.empty((cap, 6), np.float32)
+        n = C.c_int(0)
+        fh, fw = frame_hw if frame_hw is not None else (0, 0)
+        _lib.check(_lib.load().yds_nms(self._h, image, conf_thres, iou_thres, fh, fw, _lib.ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def layer_shape(self, i):
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(_lib.load().yds_darknet_layer_shape(self._h, i, C.byref(c), C.byref(h), C.byref(w)))
+        return c.value, h.value, w.value
+
+    def layer_output(self, i, batch=1):
+        c, h, w = self.layer_shape(i)
+        out = np.empty((batch, c, h, w), np.float32)
+        _lib.check(_lib.load().yds_darknet_layer_output(self._h, i, batch, _lib.ptr(out)))
+        return out
+
+    def get_input(self, batch=1):
+        out = np.empty((batch, int(self.hyperparams["channels"]), *self.img_size), np.float32)
+        _lib.check(_lib.load().yds_darknet_get_input(self._h, batch, _lib.ptr(out)))
+        return out
+
+    def set_injection(self, image, rows, logit=6.0):
+        rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, 9)
+        _lib.check(_lib.load().yds_darknet_set_injection(self._h, image, _lib.ptr(rows), rows.shape[0], logit))
+
+    def yolo_heads(self):
+        """[(H, W, [(aw, ah)...])] per yolo layer, in network order (for synth.head_injection)."""
+        heads = []
+        for i, d in enumerate(self.module_defs):
+            if d["type"] == "yolo":
+                _, h, w = self.layer_shape(i)
+                idx = [int(v) for v in d["mask"].split(",")]
+                a = [int(v) for v in d["anchors"].split(",")]
+                heads.append((h, w, [(a[2 * j], a[2 * j + 1]) for j in idx]))
+        return heads
+
+    def conv_flops(self):
+        return int(_lib.load().yds_darknet_conv_flops(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().yds_darknet_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _wrap_like(x, arr):
+    """Return a torch tensor when the caller passed one, else numpy."""
+    if hasattr(x, "detach"):
+        import torch
+        return torch.from_numpy(arr)
+    return arr
