@@ -75,6 +75,9 @@ int yds_darknet_get_input(yds_net *, int batch, float *nchw_host);              
  * rows: [n,9] fp32 = head, anchor, gy, gx, tx, ty, tw, th, cls ; image selects the batch slot.
  * Applied on every following forward until cleared with n = 0. */
 int yds_darknet_set_injection(yds_net *, int image, const float *rows_host, int n, float logit);
+/* preload n_sets x batch_max injection tables (offsets: n_sets*batch_max+1 row offsets) and pick one per step */
+int yds_darknet_load_injection_sets(yds_net *, const float *rows_host, const int32_t *offsets_host, int n_sets, float logit);
+int yds_darknet_select_injection_set(yds_net *, int set);
 
 /* ---- post-processing: soft_non_max_suppression + resize_boxes ---------------------------
  * yds_nms <- yolo3/utils/model_build.py:52-137 (multi-label hard NMS, class offset 4096,
@@ -154,9 +157,11 @@ int yds_pipeline_step(yds_pipe *, const uint8_t *frames_dev, int h, int w, int b
                       int32_t *out6_host, int cap, int32_t *counts_host);
 /* per-stage device time of the last step in microseconds: resize, detector, decode+nms, reid, assoc */
 int yds_pipeline_stage_us(yds_pipe *, float *us5);
-/* average duration (us) and launch count of the implicit-GEMM conv kernel since the last reset,
- * measured with HIP events on the handle's stream */
-int yds_conv_timing(yds_net *, int reset, double *total_us, int64_t *launches, double *flops);
+/* Per tile-variant totals of the implicit-GEMM conv kernel (4 instantiations, yds_conv_variant_name):
+ * duration in us, launch count and algorithmic flops, measured with HIP events recorded around every
+ * launch on the handle's stream.  mode 1 = zero the counters and start timing, 2 = stop, 0 = read. */
+int yds_conv_timing(yds_net *, int mode, double *total_us4, int64_t *launches4, double *flops4);
+const char *yds_conv_variant_name(int variant);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,62 @@
+"""End-to-end hot path (csrc/pipeline.cpp through the C ABI) vs the oracle pipeline on the same frames."""
+import numpy as np
+import pytest
+
+from yolo_deepsort_amd import cfgs, synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+DS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
+
+
+@pytest.mark.parametrize("name,size,batch", [("yolov3-tiny", 416, 4), ("yolov4-tiny", 416, 3)])
+def test_pipeline_matches_oracle_stream(name, size, batch):
+    from oracle.darknet import DarknetOracle
+    from oracle.pipeline import run_stream
+    from yolo_deepsort_amd import _lib, pipeline as pl
+    from yolo_deepsort_amd.deep_sort import DeepSort
+    from yolo_deepsort_amd.models import Darknet
+    _lib.init(0)
+    cfg = cfgs.cfg_text(name, size, size)
+    blob = synth.darknet_weights_blob(cfg, 0)
+    net = Darknet(None, img_size=(size, size), batch_max=batch, cfg_text=cfg)
+    net.load_darknet_weights(None, blob=blob)
+    sd = synth.reid_state_dict(0)
+    ds = DeepSort(sd, use_cuda=True, **DS)
+    scene = synth.PersonScene(10, frame_hw=(480, 640), seed=3, occlude_frac=0.2)
+    n = 4 * batch
+    frames = np.stack([scene.frame(t) for t in range(n)], 0)
+    heads = net.yolo_heads()
+    # every third person is a "car" (class 2), one a class the mask drops (class 5)
+    inj = []
+    for t in range(n):
+        ids, tlwh = scene.boxes(t)
+        rows = synth.head_injection(tlwh, (480, 640), (size, size), heads)
+        rows[:, 8] = np.where(ids % 3 == 0, 2, 0)
+        rows[ids == 4, 8] = 5
+        inj.append(rows)
+    inj[5] = inj[5][:0]                         # a frame where the detector returns None
+    pl.load_injection_sets(net, [[inj[s * batch + b] for b in range(batch)] for s in range(n // batch)])
+    pipe = pl.Pipeline(net, ds, 0.5, 0.4, class_mask=[0, 2, 4])
+    dev = _lib.DeviceBuffer.from_array(frames)
+    got = []
+    for s in range(n // batch):
+        pl.select_injection_set(net, s)
+        got += pipe.step(dev.offset(s * batch * frames[0].nbytes), 480, 640, batch)
+    ref_net = DarknetOracle(cfg, size, is_text=True)
+    ref_net.load_weights_array(np.frombuffer(blob, dtype=F32, offset=20))
+    want = run_stream(ref_net, sd, DS, frames, inj)
+    assert len(got) == len(want) == n
+    seen_rows = 0
+    for t, (g, w) in enumerate(zip(got, want)):
+        if w is None:
+            assert g is None, t
+            continue
+        w = np.array(w, np.int32).reshape(-1, 6)
+        assert g.shape == w.shape, (t, g, w)
+        assert np.array_equal(g[:, 4:], w[:, 4:]), t              # track ids and classes: bit exact
+        assert np.abs(g[:, :4] - w[:, :4]).max(initial=0) <= 1, t
+        seen_rows += len(w)
+    assert got[5] is None and seen_rows > 5 * 8
+    st = pipe.stage_us()
+    assert st["detector"] > 0

@@ -1,0 +1,159 @@
+"""CPU tests of host-side logic: loaders, cfg generators, action module, multi-process plumbing."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_reference
+from yolo_deepsort_amd import cfgs, loaders, synth
+
+
+def test_parse_model_config_matches_oracle_restatement():
+    from oracle.cfg import parse_model_config_text
+    for name in cfgs.CFG_BUILDERS:
+        text = cfgs.cfg_text(name)
+        assert loaders.parse_model_config(None, text=text) == parse_model_config_text(text)
+    d = loaders.parse_model_config(None, text="[net]\nchannels=3\n# c\n\n[convolutional]\n filters = 8 \nsize=1\n")
+    assert d[1] == {"type": "convolutional", "batch_normalize": 0, "filters": "8", "size": "1"}
+
+
+def test_load_classes_drops_last_element():
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+    names = loaders.load_classes(f.name)
+    os.unlink(f.name)
+    assert len(names) == 80 and names[0] == "person" and names[2] == "car" and names[-1] == "toothbrush"
+
+
+def test_reid_checkpoint_roundtrip_zip_and_legacy():
+    import torch
+    sd = synth.reid_state_dict(0)
+    assert len(sd) == 130
+    for legacy in (False, True):
+        with tempfile.NamedTemporaryFile(suffix=".t7", delete=False) as f:
+            pass
+        torch.save({"net_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "acc": 0.5, "epoch": 1},
+                   f.name, _use_new_zipfile_serialization=not legacy)
+        back = loaders.load_reid_checkpoint(f.name)
+        os.unlink(f.name)
+        assert set(back) == set(sd)
+        for k in sd:
+            assert np.array_equal(back[k], sd[k]), k
+
+
+def test_weight_blob_layout():
+    from oracle.darknet import DarknetOracle
+    text = cfgs.cfg_text("yolov3-tiny")
+    blob = synth.darknet_weights_blob(text, 0)
+    assert len(blob) == 35434956            # canonical yolov3-tiny.weights size
+    net = DarknetOracle(text, 416, is_text=True)
+    assert net.load_weights_array(np.frombuffer(blob, dtype=np.float32, offset=20)) * 4 + 20 == len(blob)
+    # head objectness bias lands on channels 4, 89, 174
+    head = net.params[15]
+    assert np.allclose(head["bias"][4::85], -4.0)
+
+
+def test_scene_is_deterministic_and_bounded():
+    a, b = synth.PersonScene(30, seed=0), synth.PersonScene(30, seed=0)
+    for t in (0, 7, 133):
+        ia, ba = a.boxes(t)
+        ib, bb = b.boxes(t)
+        assert np.array_equal(ia, ib) and np.array_equal(ba, bb)
+        assert (ba[:, 0] >= 0).all() and (ba[:, 0] + ba[:, 2] <= 1920 + 1e-3).all()
+        assert (ba[:, 1] >= 0).all() and (ba[:, 1] + ba[:, 3] <= 1080 + 1e-3).all()
+        assert np.array_equal(a.features(t), b.features(t))
+    f = a.frame(3)
+    assert f.shape == (1080, 1920, 3) and f.dtype == np.uint8
+    crowd = synth.PersonScene(200, seed=0, n_visible=150)
+    assert len(crowd.boxes(5)[0]) == 150
+
+
+def test_head_injection_decodes_back_to_boxes():
+    """Injected logits must decode (oracle YOLO decode) to the scripted boxes."""
+    from oracle.darknet import yolo_decode
+    V3 = [(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]
+    heads = [(19, 19, V3[0]), (38, 38, V3[1]), (76, 76, V3[2])]
+    scene = synth.PersonScene(30, seed=0)
+    _, tlwh = scene.boxes(0)
+    rows = synth.head_injection(tlwh, (1080, 1920), (608, 608), heads)
+    assert rows.shape == (30, 9)
+    for r, (x, y, w, h) in zip(rows, tlwh):
+        hi, a, gy, gx = (int(v) for v in r[:4])
+        H, W, anchors = heads[hi]
+        t = np.full((1, 3 * 85, H, W), -6.0, np.float32)
+        t[0, a * 85:a * 85 + 4, gy, gx] = r[4:8]
+        box = yolo_decode(t, anchors, 80, (608, 608))[0, a * H * W + gy * W + gx, :4]
+        want = np.array([(x + w / 2) * 608 / 1920, (y + h / 2) * 608 / 1080, w * 608 / 1920, h * 608 / 1080])
+        np.testing.assert_allclose(box, want, rtol=2e-3, atol=0.05)
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not has_reference(), reason="reference tree not present")
+def test_action_module_matches_reference():
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import ref_harness
+from yolo_deepsort_amd import action as mine
+ref_harness.install_shims()
+sys.path.insert(0, ref_harness.REF_ROOT)
+for k in [k for k in sys.modules if k.split(".")[0] == "action"]:
+    del sys.modules[k]
+import action.action_Identify as rai, action.actions as ra
+assert ra.__file__.startswith(ref_harness.REF_ROOT)
+def mk(mod):
+    return [mod.TakeOff(0, (1, 2)), mod.Landing(0, (1, 2)), mod.Glide(0, (2, 4)), mod.BreakInto(0, 2), mod.BreakInto(2, 1)]
+A = rai.ActionIdentify(mk(ra), max_age=3, max_size=4)
+B = mine.ActionIdentify(mk(mine), max_age=3, max_size=4)
+rng = np.random.RandomState(0)
+pos = rng.randint(0, 500, (6, 2)).astype(float)
+vel = rng.randint(-6, 7, (6, 2)).astype(float)
+for t in range(40):
+    pos += vel
+    if t %% 7 == 0: vel = rng.randint(-6, 7, (6, 2)).astype(float)
+    vis = [i for i in range(6) if rng.rand() > 0.25]
+    det = np.array([[pos[i, 0], pos[i, 1], pos[i, 0] + 20, pos[i, 1] + 40, i + 1, (i %% 2) * 2] for i in vis], np.int32).reshape(-1, 6)
+    ra_out, rb_out = A.update(det), B.update(det)
+    assert [(int(a), int(b), c) for a, b, c in ra_out] == [(int(a), int(b), c) for a, b, c in rb_out], (t, ra_out, rb_out)
+assert A.update(None) is None and B.update(None) is None
+print("OK")
+''' % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_two_rank_gloo_stream_sharding():
+    """N>1 path on CPU: rendezvous, barriers, max-over-ranks timing and per-rank stream seeds."""
+    code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+from yolo_deepsort_amd.dist import Ranks
+from yolo_deepsort_amd import synth
+r = Ranks("gloo")
+assert r.world == 2
+scene = synth.PersonScene(5, seed=r.stream_seed())
+ids, boxes = scene.boxes(0)
+r.barrier()
+dt = r.max_over_ranks(1.0 + r.rank)            # slowest rank defines the job time
+tot = r.sum_over_ranks(float(boxes[:, 0].sum()))
+frames = r.total_frames(10, 8)
+if r.rank == 0:
+    other = synth.PersonScene(5, seed=1).boxes(0)[1]
+    assert dt == 2.0 and frames == 160
+    assert abs(tot - float(boxes[:, 0].sum()) - float(other[:, 0].sum())) < 1e-3
+    print("OK", frames / dt)
+r.shutdown()
+''' % ROOT
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    try:
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                              "--master-addr", "127.0.0.1", "--master-port", "29541", f.name],
+                             capture_output=True, text=True, timeout=600, env=env)
+    finally:
+        os.unlink(f.name)
+    assert out.returncode == 0 and "OK 80.0" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]

@@ -50,6 +50,9 @@ SIGNATURES = {
     "yds_darknet_layer_output": (_I, [_P, _I, _I, _P]),
     "yds_darknet_get_input": (_I, [_P, _I, _P]),
     "yds_darknet_set_injection": (_I, [_P, _I, _P, _I, _F]),
+    "yds_darknet_load_injection_sets": (_I, [_P, _P, _P, _I, _F]),
+    "yds_darknet_select_injection_set": (_I, [_P, _I]),
+    "yds_conv_variant_name": (C.c_char_p, [_I]),
     "yds_nms": (_I, [_P, _I, _F, _F, _I, _I, _P, _I, _P]),
     "yds_nms_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),
     "yds_reid_create": (_P, [_I]),

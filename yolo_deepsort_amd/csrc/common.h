@@ -88,7 +88,10 @@ struct ConvArgs {
     int ksize = 1, stride = 1, pad = 0, kpad = 0;
     int act = ACT_LINEAR, res_mode = RES_NONE;
 };
-void launch_conv(const ConvArgs &a, hipStream_t s);
+// returns the tile-variant id that was launched (0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32)
+int launch_conv(const ConvArgs &a, hipStream_t s);
+constexpr int kConvVariants = 4;
+const char *conv_variant_name(int v);
 double conv_flops(const ConvArgs &a);
 
 // ---- simple layers (layers.hip) --------------------------------------------------------------

@@ -194,7 +194,12 @@ double conv_flops(const ConvArgs &a) {
     return 2.0 * (double)a.y.pixels() * a.y.c * a.ksize * a.ksize * a.x.c;
 }
 
-void launch_conv(const ConvArgs &a, hipStream_t s) {
+const char *conv_variant_name(int v) {
+    static const char *names[kConvVariants] = {"conv_igemm_f32<128,128,2,2>", "conv_igemm_f32<128,64,2,2>", "conv_igemm_f32<64,64,2,2>", "conv_igemm_f32<128,32,4,1>"};
+    return v >= 0 && v < kConvVariants ? names[v] : "?";
+}
+
+int launch_conv(const ConvArgs &a, hipStream_t s) {
     ConvKernelArgs k;
     k.x = a.x.p; k.w = a.w; k.bias = a.bias; k.res = a.res.p; k.y = a.y.p;
     k.H = a.x.h; k.W = a.x.w; k.Cin = a.x.c; k.ldx = a.x.ld;
@@ -212,14 +217,17 @@ void launch_conv(const ConvArgs &a, hipStream_t s) {
     auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     if (N <= 32) {
         launch_cfg<128, 32, 4, 1>(k, s);
-    } else if (N <= 64) {
-        if (blocks(128, 64) >= 256) launch_cfg<128, 64, 2, 2>(k, s);
-        else launch_cfg<64, 64, 2, 2>(k, s);
-    } else {
-        if (blocks(128, 128) >= 384) launch_cfg<128, 128, 2, 2>(k, s);
-        else if (blocks(128, 64) >= 384) launch_cfg<128, 64, 2, 2>(k, s);
-        else launch_cfg<64, 64, 2, 2>(k, s);
+        return 3;
     }
+    if (N <= 64) {
+        if (blocks(128, 64) >= 256) { launch_cfg<128, 64, 2, 2>(k, s); return 1; }
+        launch_cfg<64, 64, 2, 2>(k, s);
+        return 2;
+    }
+    if (blocks(128, 128) >= 384) { launch_cfg<128, 128, 2, 2>(k, s); return 0; }
+    if (blocks(128, 64) >= 384) { launch_cfg<128, 64, 2, 2>(k, s); return 1; }
+    launch_cfg<64, 64, 2, 2>(k, s);
+    return 2;
 }
 
 }  // namespace yds

@@ -343,15 +343,15 @@ void Darknet::run_graph(int batch) {
             a.act = l.act;
             if (l.fused_res >= 0) { a.res = view(l.fused_res, batch); a.res_mode = RES_AFTER_ACT; }
             if (time_convs) YDS_HIP(hipEventRecord(ev0, stream));
-            launch_conv(a, stream);
+            int variant = launch_conv(a, stream);
             if (time_convs) {
                 YDS_HIP(hipEventRecord(ev1, stream));
                 YDS_HIP(hipEventSynchronize(ev1));
                 float ms = 0;
                 YDS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-                conv_us += ms * 1e3;
-                conv_launches++;
-                conv_flops_acc += conv_flops(a);
+                conv_us[variant] += ms * 1e3;
+                conv_launches[variant]++;
+                conv_flops_acc[variant] += conv_flops(a);
             }
         } else if (l.type == "maxpool") {
             launch_maxpool(view(l.src, batch), view(i, batch), l.ksize, l.stride, l.pad, l.zero_br, stream);
@@ -372,8 +372,14 @@ void Darknet::run_graph(int batch) {
             View head = view(l.src, batch);
             int hidx = 0;
             for (int y : yolo_layers) { if (y == i) break; ++hidx; }
-            for (int b = 0; b < batch; ++b)
-                if (inject_active) launch_inject(head, b, inject_rows[b].p, inject_n[b], hidx, l.classes, inject_logit, stream);
+            for (int b = 0; b < batch && inject_active; ++b) {
+                if (inject_set >= 0) {
+                    int o0 = inject_offsets[inject_set * batch_max + b], o1 = inject_offsets[inject_set * batch_max + b + 1];
+                    launch_inject(head, b, inject_table.p + (size_t)o0 * 9, o1 - o0, hidx, l.classes, inject_logit, stream);
+                } else {
+                    launch_inject(head, b, inject_rows[b].p, inject_n[b], hidx, l.classes, inject_logit, stream);
+                }
+            }
             launch_yolo_decode(head, out.p, total_boxes, l.box_off, l.classes, l.anchors.data(), (int)l.anchors.size() / 2, img_h, img_w, stream);
         }
     }
@@ -433,6 +439,24 @@ void Darknet::set_injection(int image, const float *rows, int n, float logit) {
     inject_logit = logit;
     inject_active = false;
     for (int b = 0; b < batch_max; ++b) inject_active |= inject_n[b] > 0;
+}
+
+void Darknet::load_injection_sets(const float *rows, const int *offsets, int n_sets, float logit) {
+    if (n_sets <= 0) { inject_set = -1; inject_active = false; inject_offsets.clear(); return; }
+    inject_offsets.assign(offsets, offsets + (size_t)n_sets * batch_max + 1);
+    inject_table.ensure((size_t)inject_offsets.back() * 9 + 9);
+    inject_table.upload(rows, (size_t)inject_offsets.back() * 9, stream);
+    YDS_HIP(hipStreamSynchronize(stream));
+    inject_logit = logit;
+    inject_set = 0;
+    inject_active = true;
+}
+
+void Darknet::select_injection_set(int set) {
+    if (inject_offsets.empty()) fail("inject: no sets loaded");
+    int n_sets = (int)(inject_offsets.size() - 1) / batch_max;
+    if (set < 0 || set >= n_sets) fail("inject: set %d outside [0,%d)", set, n_sets);
+    inject_set = set;
 }
 
 int64_t Darknet::flops_per_image() const {
@@ -511,14 +535,30 @@ int yds_darknet_set_injection(yds_net *n, int image, const float *rows, int cnt,
     n->d->set_injection(image, rows, cnt, logit);
     YDS_API_END
 }
-int yds_conv_timing(yds_net *n, int reset, double *total_us, int64_t *launches, double *flops) {
+int yds_conv_timing(yds_net *n, int mode, double *total_us4, int64_t *launches4, double *flops4) {
     YDS_API_BEGIN
     Darknet *d = n->d;
-    if (total_us) *total_us = d->conv_us;
-    if (launches) *launches = d->conv_launches;
-    if (flops) *flops = d->conv_flops_acc;
-    if (reset == 1) { d->conv_us = 0; d->conv_launches = 0; d->conv_flops_acc = 0; d->enable_conv_timing(true); }
-    if (reset == 2) d->enable_conv_timing(false);
+    for (int v = 0; v < yds::kConvVariants; ++v) {
+        if (total_us4) total_us4[v] = d->conv_us[v];
+        if (launches4) launches4[v] = d->conv_launches[v];
+        if (flops4) flops4[v] = d->conv_flops_acc[v];
+    }
+    if (mode == 1) {
+        for (int v = 0; v < yds::kConvVariants; ++v) { d->conv_us[v] = 0; d->conv_launches[v] = 0; d->conv_flops_acc[v] = 0; }
+        d->enable_conv_timing(true);
+    }
+    if (mode == 2) d->enable_conv_timing(false);
+    YDS_API_END
+}
+const char *yds_conv_variant_name(int v) { return yds::conv_variant_name(v); }
+int yds_darknet_load_injection_sets(yds_net *n, const float *rows_host, const int32_t *offsets_host, int n_sets, float logit) {
+    YDS_API_BEGIN
+    n->d->load_injection_sets(rows_host, offsets_host, n_sets, logit);
+    YDS_API_END
+}
+int yds_darknet_select_injection_set(yds_net *n, int set) {
+    YDS_API_BEGIN
+    n->d->select_injection_set(set);
     YDS_API_END
 }
 

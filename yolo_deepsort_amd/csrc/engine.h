@@ -56,6 +56,8 @@ public:
     void layer_output_host(int layer, int batch, float *nchw);
     void get_input_host(int batch, float *nchw);
     void set_injection(int image, const float *rows, int n, float logit);
+    void load_injection_sets(const float *rows, const int *offsets, int n_sets, float logit);
+    void select_injection_set(int set);
     void enable_conv_timing(bool on);
     int64_t flops_per_image() const;
     size_t weight_floats() const;
@@ -77,12 +79,15 @@ public:
     std::vector<DevBuf<float>> inject_rows;
     std::vector<int> inject_n;
     bool inject_active = false;
+    DevBuf<float> inject_table;              // preloaded sets: rows of all (set, image) pairs
+    std::vector<int> inject_offsets;         // n_sets * batch_max + 1 row offsets into inject_table
+    int inject_set = -1;
     float inject_logit = 6.f;
     // conv timing (HIP events on this stream)
     bool time_convs = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double conv_us = 0, conv_flops_acc = 0;
-    int64_t conv_launches = 0;
+    double conv_us[kConvVariants] = {0, 0, 0, 0}, conv_flops_acc[kConvVariants] = {0, 0, 0, 0};
+    int64_t conv_launches[kConvVariants] = {0, 0, 0, 0};
 
 private:
     void run_graph(int batch);

@@ -121,7 +121,7 @@ void ReidNet::forward(int D) {
         a.x = x; a.y = y; a.w = c.wt.p; a.bias = c.bias.p;
         a.ksize = c.k; a.stride = c.stride; a.pad = c.pad; a.kpad = c.kpad; a.act = act;
         if (res) { a.res = *res; a.res_mode = res_mode; }
-        launch_conv(a, stream);
+        (void)launch_conv(a, stream);
         conv_flops_last += conv_flops(a);
     };
     View x0 = mk(in, CROP_H, CROP_W, 4);

@@ -1,0 +1,69 @@
+"""Whole-path driver used by bench.py and smoke(): frames resident in HBM -> detector over a batch ->
+per frame NMS, class mask, ReID, tracker (csrc/pipeline.cpp; reference yolo3/detect/video_detect.py:134-157)."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class Pipeline:
+    def __init__(self, net, deepsort, conf_thres=0.5, nms_thres=0.4, class_mask=None, cap=512):
+        self.net, self.ds, self.cap = net, deepsort, int(cap)
+        mask = np.ascontiguousarray(class_mask if class_mask is not None else [], dtype=np.int32)
+        self._h = _lib.check_ptr(_lib.load().yds_pipeline_create(net._h, deepsort.extractor._h, deepsort.tracker._h,
+                                                                 conf_thres, nms_thres,
+                                                                 _lib.ptr(mask) if mask.size else None, int(mask.size)))
+
+    def step(self, frames_dev, h, w, batch):
+        """frames_dev: device pointer to uint8 [batch,h,w,3].  Returns list of int32 [m,6] (or None when the
+        detector found nothing and the tracker was not called)."""
+        out = np.zeros((batch, self.cap, 6), np.int32)
+        counts = np.zeros(batch, np.int32)
+        _lib.check(_lib.load().yds_pipeline_step(self._h, frames_dev, h, w, batch, _lib.ptr(out), self.cap, _lib.ptr(counts)))
+        return [None if counts[b] < 0 else out[b, :counts[b]].copy() for b in range(batch)]
+
+    def stage_us(self):
+        us = np.zeros(5, np.float32)
+        _lib.check(_lib.load().yds_pipeline_stage_us(self._h, _lib.ptr(us)))
+        return dict(zip(("resize", "detector", "decode_nms", "reid", "assoc"), us.tolist()))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().yds_pipeline_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def conv_timing(net, mode=0):
+    """Per tile-variant (total_us, launches, flops, name) of the conv kernel; mode 1 resets+starts, 2 stops."""
+    lib = _lib.load()
+    us = (C.c_double * 4)()
+    n = (C.c_int64 * 4)()
+    fl = (C.c_double * 4)()
+    _lib.check(lib.yds_conv_timing(net._h, mode, us, n, fl))
+    return [dict(name=lib.yds_conv_variant_name(v).decode(), us=us[v], launches=n[v], flops=fl[v]) for v in range(4)]
+
+
+def load_injection_sets(net, sets, logit=6.0):
+    """sets: list (per step) of lists (per batch slot) of [n,9] arrays."""
+    bm = net.batch_max
+    rows, offsets = [], [0]
+    for s in sets:
+        assert len(s) == bm, "every set needs one table per batch slot"
+        for r in s:
+            r = np.asarray(r, np.float32).reshape(-1, 9)
+            rows.append(r)
+            offsets.append(offsets[-1] + r.shape[0])
+    rows = np.ascontiguousarray(np.concatenate(rows, 0) if rows else np.zeros((0, 9), np.float32))
+    off = np.ascontiguousarray(offsets, dtype=np.int32)
+    _lib.check(_lib.load().yds_darknet_load_injection_sets(net._h, _lib.ptr(rows), _lib.ptr(off), len(sets), logit))
+
+
+def select_injection_set(net, i):
+    _lib.check(_lib.load().yds_darknet_select_injection_set(net._h, int(i)))
