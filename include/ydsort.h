@@ -146,22 +146,32 @@ int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_ho
                         const float *feats_host, int D, int dim, float *out_TxD_host);
 
 /* ---- pipeline: VideoDetector.detect hot glue (video_detect.py:134-157) ----------------------
- * One stream: detector over `batch` consecutive frames, then per frame NMS -> class mask ->
- * p1p2Toxywh -> ReID -> tracker step, in frame order.  Frames are already resident in HBM.
+ * One stream of frames: detector over `batch` consecutive frames, NMS of every frame, class mask,
+ * p1p2Toxywh, ONE ReID pass over the crops of the whole batch, then the tracker frame by frame, in order.
+ * Frames are already resident in HBM.  next_frames_dev (optional, may be NULL): the frames of the
+ * following call; their detector pass is enqueued early so that it overlaps this call's association
+ * (the following call must then pass the same pointer and batch as frames_dev).
  * class_mask: list of class ids kept (NULL/0 = keep all).  out6: [batch, cap, 6] int32,
  * counts[batch] rows per frame (-1 = detector returned None, tracker not called). */
 yds_pipe *yds_pipeline_create(yds_net *, yds_reid *, yds_trk *, float conf_thres, float nms_thres,
                               const int32_t *class_mask, int n_mask);
 void yds_pipeline_destroy(yds_pipe *);
-int yds_pipeline_step(yds_pipe *, const uint8_t *frames_dev, int h, int w, int batch,
-                      int32_t *out6_host, int cap, int32_t *counts_host);
-/* per-stage device time of the last step in microseconds: resize, detector, decode+nms, reid, assoc */
+int yds_pipeline_step(yds_pipe *, const uint8_t *frames_dev, const uint8_t *next_frames_dev, int h, int w,
+                      int batch, int32_t *out6_host, int cap, int32_t *counts_host);
+/* bench-only: injection set (yds_darknet_load_injection_sets) to select before the prefetched detector pass */
+int yds_pipeline_set_next_injection(yds_pipe *, int set);
+/* last step, microseconds: resize (device), detector (device), host wall until NMS results, ReID, association */
 int yds_pipeline_stage_us(yds_pipe *, float *us5);
-/* Per tile-variant totals of the implicit-GEMM conv kernel (4 instantiations, yds_conv_variant_name):
+/* Per tile-variant totals of the implicit-GEMM conv kernel (yds_conv_num_variants instantiations):
  * duration in us, launch count and algorithmic flops, measured with HIP events recorded around every
  * launch on the handle's stream.  mode 1 = zero the counters and start timing, 2 = stop, 0 = read. */
-int yds_conv_timing(yds_net *, int mode, double *total_us4, int64_t *launches4, double *flops4);
+int yds_conv_timing(yds_net *, int mode, double *total_us, int64_t *launches, double *flops);
+int yds_conv_num_variants(void);
 const char *yds_conv_variant_name(int variant);
+/* Kernel tuning aid: time `iters` launches of one conv layer on random data (HIP events); returns the
+ * average launch duration in us and the tile variant that was picked. */
+int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual,
+                   int iters, double *avg_us, int *variant);
 
 #ifdef __cplusplus
 }

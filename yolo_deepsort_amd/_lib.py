@@ -53,6 +53,8 @@ SIGNATURES = {
     "yds_darknet_load_injection_sets": (_I, [_P, _P, _P, _I, _F]),
     "yds_darknet_select_injection_set": (_I, [_P, _I]),
     "yds_conv_variant_name": (C.c_char_p, [_I]),
+    "yds_conv_num_variants": (_I, []),
+    "yds_conv_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "yds_nms": (_I, [_P, _I, _F, _F, _I, _I, _P, _I, _P]),
     "yds_nms_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),
     "yds_reid_create": (_P, [_I]),
@@ -80,7 +82,8 @@ SIGNATURES = {
     "yds_cosine_min_cost": (_I, [_P, _P, _I, _P, _I, _I, _P]),
     "yds_pipeline_create": (_P, [_P, _P, _P, _F, _F, _P, _I]),
     "yds_pipeline_destroy": (None, [_P]),
-    "yds_pipeline_step": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
+    "yds_pipeline_step": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "yds_pipeline_set_next_injection": (_I, [_P, _I]),
     "yds_pipeline_stage_us": (_I, [_P, _P]),
     "yds_conv_timing": (_I, [_P, _I, _P, _P, _P]),
 }

@@ -88,9 +88,11 @@ struct ConvArgs {
     int ksize = 1, stride = 1, pad = 0, kpad = 0;
     int act = ACT_LINEAR, res_mode = RES_NONE;
 };
-// returns the tile-variant id that was launched (0: 128x128, 1: 128x64, 2: 64x64, 3: 128x32)
-int launch_conv(const ConvArgs &a, hipStream_t s);
-constexpr int kConvVariants = 4;
+// returns the tile-variant id that was launched (see conv_variant_name)
+int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice
+int conv_default_variant(const ConvArgs &a);
+int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us);   // measured fastest variant
+constexpr int kConvVariants = 7;
 const char *conv_variant_name(int v);
 double conv_flops(const ConvArgs &a);
 
@@ -109,7 +111,8 @@ void launch_inject(const View &head, int image, const float *rows_dev, int n, in
 // stretch-resize uint8 HWC frames to NHWC4 fp32 in [0,1] (4th channel 0)
 void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s);
 // ReID: crop + resize to 64x128 + /255 + mean/std -> NHWC4
-void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyxy_dev, int D, const View &y,
+// boxes: [D,5] = x1,y1,x2,y2,frame index (frames are h*w*3 bytes apart)
+void launch_crop_resize(const uint8_t *frames, int h, int w, const int *boxes5_dev, int D, const View &y,
                         hipStream_t s);
 void launch_avgpool_l2norm(const View &x, float *out, hipStream_t s);         // [D,8,4,512] -> [D,512]
 

@@ -16,6 +16,9 @@
 //   Epilogue: bias + activation (+ residual, before or after the activation) and 128-byte row stores.
 #include "common.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace yds {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -29,28 +32,38 @@ struct ConvKernelArgs {
     int ksize, stride, pad;
     int K, Kpad, M;
     int act, res_mode;
+    // XCD-aware tile map: the 8 XCDs own an xm x xn grid of rectangles of rm x rn tiles (workgroup id % 8 = XCD)
+    int tiles_m, tiles_n, xm, rm, rn;
 };
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
+constexpr int KALIGN = 32;                // weight rows are zero padded to a multiple of this
+#ifndef YDS_STAGGER
+#define YDS_STAGGER 24
+#endif
+constexpr int STAGGER = YDS_STAGGER;     // s_sleep units of 64 clocks
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case ACT_LEAKY: return v > 0.f ? v : v * 0.1f;
-        case ACT_RELU: return v > 0.f ? v : 0.f;
-        case ACT_MISH: {
-            float sp = v > 20.f ? v : log1pf(expf(v));
-            return v * tanhf(sp);
-        }
-        default: return v;
+template <int ACT> __device__ __forceinline__ float apply_act(float v) {
+    if (ACT == ACT_LEAKY) return v > 0.f ? v : v * 0.1f;
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_MISH) {
+        float sp = v > 20.f ? v : log1pf(expf(v));
+        return v * tanhf(sp);
     }
+    return v;
 }
 
-template <int BM, int BN, int WM, int WN>
+// ABL (tuning ablations, compile time): 1 = no global loads in the loop, 2 = no LDS stores / barrier, 4 = no
+// fragment reads from LDS in the loop, 8 = no MFMA.  0 in production.
+template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BK == 16 || BK == 32, "K step");
+    constexpr int LDS_LD = BK + 4;                      // padded row: conflict-free ds_read_b128 fragments
+    constexpr int CPR = BK / 4;                         // float4 chunks per staged row
+    constexpr int RPP = 256 / CPR;                      // rows staged per pass of the 256 threads
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;   // float4 rows per thread per K step
+    constexpr int A_ROWS = BM / RPP, B_ROWS = BN / RPP; // float4 rows per thread per K step
+    static_assert(A_ROWS >= 1 && B_ROWS >= 1, "tile too small for the staging pattern");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                                   // [2][BM][LDS_LD]
     float *Bs = smem + 2 * BM * LDS_LD;                 // [2][BN][LDS_LD]
@@ -58,18 +71,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // blockIdx.x walks M fastest so that neighbouring workgroups share the weight tile in L2
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 and every XCD has a private
+    // 4 MiB L2, so each XCD gets a compact rm x rn rectangle of tiles (small A-rows + B-columns footprint per
+    // K step) instead of a stripe through the whole problem.  Placement only affects speed, never results.
+    int m0, n0;
+    {
+        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+        const int tm = (xcd % p.xm) * p.rm + idx % p.rm, tn = (xcd / p.xm) * p.rn + idx / p.rm;
+        if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+        m0 = tm * BM;
+        n0 = tn * BN;
+    }
 
-    const int cq = tid & 7;          // which float4 of the 32-wide K step this thread stages
-    const int r0 = tid >> 3;         // first staged row; further rows at +32
+    const int cq = tid % CPR;        // which float4 of the K step this thread stages
+    const int r0 = tid / CPR;        // first staged row; further rows at +RPP
 
     // per staged A row: input pixel origin for filter tap (0,0)
     int a_base[A_ROWS], a_iy[A_ROWS], a_ix[A_ROWS];
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
-        int m = m0 + r0 + 32 * i;
+        int m = m0 + r0 + RPP * i;
         if (m < p.M) {
             int img = m / HoWo, rem = m - img * HoWo;
             int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -86,34 +108,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     int kk = cq * 4, kh = 0, kw = 0, kc = kk;
     while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
 
-    f32x4 a_reg[A_ROWS], b_reg[B_ROWS];
-    auto load_tiles = [&]() {
+    // Global -> register staging, two tiles deep: while tile t feeds the MFMAs out of LDS, tile t+1 sits in one
+    // register set (landing or landed) and the loads of tile t+2 are issued into the other.  A K step is
+    // ~4-8k clocks of MFMA time, one L2/MALL round trip under load is of the same order, so one tile of
+    // prefetch distance left the matrix pipe waiting on vmcnt.  Loads are branch free: out-of-image taps read a
+    // safe address and are zeroed when the tile is written to LDS; rows past M / Cout read a clamped row and
+    // only feed accumulators that are never stored.
+    f32x4 a_reg[2][A_ROWS], b_reg[2][B_ROWS];
+    unsigned a_ok[2] = {0u, 0u};
+    const float *w_row[B_ROWS];
+#pragma unroll
+    for (int i = 0; i < B_ROWS; ++i) w_row[i] = p.w + (size_t)min(n0 + r0 + RPP * i, p.Cout - 1) * p.Kpad;
+    auto load_tiles = [&](auto set_tag) {
+        constexpr int S = decltype(set_tag)::value;
         const int tap_off = (kh * p.W + kw) * p.ldx + kc;
         const bool k_ok = kk < p.K;
+        unsigned okm = 0;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
             bool ok = k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            a_reg[i] = ok ? *reinterpret_cast<const f32x4 *>(p.x + (a_base[i] + tap_off)) : f32x4{0, 0, 0, 0};
+            okm |= (ok ? 1u : 0u) << i;
+            a_reg[S][i] = *reinterpret_cast<const f32x4 *>(p.x + (ok ? a_base[i] + tap_off : 0));
         }
+        a_ok[S] = okm;
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) {
-            int n = n0 + r0 + 32 * i;
-            b_reg[i] = n < p.Cout ? *reinterpret_cast<const f32x4 *>(p.w + (size_t)n * p.Kpad + kk) : f32x4{0, 0, 0, 0};
-        }
+        for (int i = 0; i < B_ROWS; ++i) b_reg[S][i] = *reinterpret_cast<const f32x4 *>(w_row[i] + kk);
     };
     auto advance_k = [&]() {
         kk += BK;
         kc += BK;
         while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](auto set_tag, int buf) {
+        constexpr int S = decltype(set_tag)::value;
         float *a = As + buf * BM * LDS_LD, *b = Bs + buf * BN * LDS_LD;
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) *reinterpret_cast<f32x4 *>(a + (r0 + 32 * i) * LDS_LD + cq * 4) = a_reg[i];
+        for (int i = 0; i < A_ROWS; ++i) {
+            f32x4 v = a_reg[S][i];
+            if (!((a_ok[S] >> i) & 1u)) v = f32x4{0, 0, 0, 0};
+            *reinterpret_cast<f32x4 *>(a + (r0 + RPP * i) * LDS_LD + cq * 4) = v;
+        }
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<f32x4 *>(b + (r0 + 32 * i) * LDS_LD + cq * 4) = b_reg[i];
+        for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<f32x4 *>(b + (r0 + RPP * i) * LDS_LD + cq * 4) = b_reg[S][i];
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -123,37 +163,60 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = p.Kpad / BK;
-    load_tiles();
-    store_tiles(0);
+    const int nk = (p.K + BK - 1) / BK;              // Kpad is a multiple of 32 >= K, so BK = 16 may stop earlier
+    load_tiles(Set0{});
+    if (nk > 1) { advance_k(); load_tiles(Set1{}); }
+    store_tiles(Set0{}, 0);
+    // Two workgroups share a CU (one wave of each per SIMD).  Left alone they run in lockstep and hit their
+    // barrier / LDS-latency gaps together, idling the matrix pipe; delaying every other resident workgroup by
+    // about half a K step makes one wave's gap fall into the other's MFMA run.  Speed only.
+    if (STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(STAGGER);
     __syncthreads();
 
     const int frag_row = lane & 31, frag_k = (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) { advance_k(); load_tiles(); }
-        const float *a = As + cur * BM * LDS_LD + (wm * (BM / WM) + frag_row) * LDS_LD + frag_k;
-        const float *b = Bs + cur * BN * LDS_LD + (wn * (BN / WN) + frag_row) * LDS_LD + frag_k;
+    const float *a_lds = As + (wm * (BM / WM) + frag_row) * LDS_LD + frag_k;
+    const float *b_lds = Bs + (wn * (BN / WN) + frag_row) * LDS_LD + frag_k;
+    f32x4 af[2][TM], bf[2][TN];                       // register double buffer for the LDS fragments
+    auto load_frags = [&](int buf, int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const f32x4 *>(a_lds + buf * BM * LDS_LD + i * 32 * LDS_LD + ks * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const f32x4 *>(b_lds + buf * BN * LDS_LD + j * 32 * LDS_LD + ks * 8);
+    };
+    load_frags(0, 0, 0);
+    // one K step; PAR = kt & 1 is compile time so that the register sets are statically indexed
+    auto k_step = [&](auto par_tag, int kt) {
+        constexpr int PAR = decltype(par_tag)::value;
+        using Free = std::integral_constant<int, PAR>;          // set that held tile kt (already in LDS)
+        using Next = std::integral_constant<int, PAR ^ 1>;      // set that holds tile kt+1
+        if (!(ABL & 1) && kt + 2 < nk) { advance_k(); load_tiles(Free{}); }
 #pragma unroll
         for (int ks = 0; ks < BK / 8; ++ks) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(a + i * 32 * LDS_LD + ks * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(b + j * 32 * LDS_LD + ks * 8);
+            if (!(ABL & 4) && ks + 1 < BK / 8) load_frags(PAR, ks + 1, (ks + 1) & 1);       // next fragments fly under these MFMAs
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][c], bf[j][c], acc[i][j], 0, 0, 0);
+                        if (ABL & 8) acc[i][j][c] += af[ks & 1][i][c] * bf[ks & 1][j][c];
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i][c], bf[ks & 1][j][c], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        __syncthreads();
+        const bool more = kt + 1 < nk;
+        if (!(ABL & 2)) {
+            if (more) store_tiles(Next{}, PAR ^ 1);
+            __syncthreads();
+        }
+        if (!(ABL & 4) && more) load_frags(PAR ^ 1, 0, 0);
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        k_step(Set0{}, kt);
+        if (kt + 1 < nk) k_step(Set1{}, kt + 1);
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    // ACT / RES are compile-time so the 16 elements of a fragment are straight-line code: residual loads are
+    // issued together, then bias + activation, then the stores.
     const int col = lane & 31, rsel = (lane >> 5) * 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -163,31 +226,63 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + wm * (BM / WM) + i * 32 + rsel;
+            float r[16];
+            if (RES != RES_NONE) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mb + (e & 3) + 8 * (e >> 2);
+                    r[e] = m < p.M ? p.res[(size_t)m * p.ldr + n] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m >= p.M) continue;
                 float v = acc[i][j][e] + bias;
-                if (p.res_mode == RES_BEFORE_ACT) v += p.res[(size_t)m * p.ldr + n];
-                v = apply_act(v, p.act);
-                if (p.res_mode == RES_AFTER_ACT) v += p.res[(size_t)m * p.ldr + n];
-                p.y[(size_t)m * p.ldy + n] = v;
+                if (RES == RES_BEFORE_ACT) v += r[e];
+                v = apply_act<ACT>(v);
+                if (RES == RES_AFTER_ACT) v += r[e];
+                if (m < p.M) p.y[(size_t)m * p.ldy + n] = v;
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN> static void launch_cfg(const ConvKernelArgs &k, hipStream_t s) {
-    constexpr size_t smem = 2ull * (BM + BN) * LDS_LD * sizeof(float);
+template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES, int ABL = 0> static void launch_inst(ConvKernelArgs k, hipStream_t s) {
+    constexpr size_t smem = 2ull * (BM + BN) * (BK + 4) * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_igemm_f32<BM, BN, WM, WN>;
+    auto kern = conv_igemm_f32<BM, BN, WM, WN, BK, ACT, RES, ABL>;
     if (!attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    dim3 grid((k.M + BM - 1) / BM, (k.Cout + BN - 1) / BN);
+    // choose the XCD grid (xm x xn = 8) with the smallest per-K-step footprint (rows*BM + cols*BN) per XCD
+    k.tiles_m = (k.M + BM - 1) / BM;
+    k.tiles_n = (k.Cout + BN - 1) / BN;
+    long best = -1;
+    for (int xm = 1; xm <= 8; xm *= 2) {
+        int xn = 8 / xm;
+        int rm = (k.tiles_m + xm - 1) / xm, rn = (k.tiles_n + xn - 1) / xn;
+        long waste = (long)rm * rn * 8 - (long)k.tiles_m * k.tiles_n;       // idle workgroup slots
+        long cost = ((long)rm * BM + (long)rn * BN) * 64 + waste * (BM + BN);
+        if (best < 0 || cost < best) { best = cost; k.xm = xm; k.rm = rm; k.rn = rn; }
+    }
+    dim3 grid(8 * k.rm * k.rn);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, k);
     YDS_HIP(hipGetLastError());
+}
+
+template <int BM, int BN, int WM, int WN, int BK> static void launch_cfg(const ConvKernelArgs &k, hipStream_t s) {
+    const int key = k.act * 4 + k.res_mode;
+    switch (key) {
+        case ACT_LINEAR * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_LINEAR, RES_NONE>(k, s);
+        case ACT_LEAKY * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_LEAKY, RES_NONE>(k, s);
+        case ACT_LEAKY * 4 + RES_AFTER_ACT: return launch_inst<BM, BN, WM, WN, BK, ACT_LEAKY, RES_AFTER_ACT>(k, s);
+        case ACT_MISH * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_MISH, RES_NONE>(k, s);
+        case ACT_MISH * 4 + RES_AFTER_ACT: return launch_inst<BM, BN, WM, WN, BK, ACT_MISH, RES_AFTER_ACT>(k, s);
+        case ACT_RELU * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_RELU, RES_NONE>(k, s);
+        case ACT_RELU * 4 + RES_BEFORE_ACT: return launch_inst<BM, BN, WM, WN, BK, ACT_RELU, RES_BEFORE_ACT>(k, s);
+        default: fail("conv: unsupported activation/residual combination (%d, %d)", k.act, k.res_mode);
+    }
 }
 
 double conv_flops(const ConvArgs &a) {
@@ -195,11 +290,13 @@ double conv_flops(const ConvArgs &a) {
 }
 
 const char *conv_variant_name(int v) {
-    static const char *names[kConvVariants] = {"conv_igemm_f32<128,128,2,2>", "conv_igemm_f32<128,64,2,2>", "conv_igemm_f32<64,64,2,2>", "conv_igemm_f32<128,32,4,1>"};
+    static const char *names[kConvVariants] = {"conv_igemm_f32<128,128,2,2,32>", "conv_igemm_f32<128,64,2,2,32>", "conv_igemm_f32<64,64,2,2,32>",
+                                               "conv_igemm_f32<128,32,4,1,32>", "conv_igemm_f32<128,128,2,2,16>", "conv_igemm_f32<128,64,2,2,16>",
+                                               "conv_igemm_f32<64,128,2,2,16>"};
     return v >= 0 && v < kConvVariants ? names[v] : "?";
 }
 
-int launch_conv(const ConvArgs &a, hipStream_t s) {
+static ConvKernelArgs make_args(const ConvArgs &a) {
     ConvKernelArgs k;
     k.x = a.x.p; k.w = a.w; k.bias = a.bias; k.res = a.res.p; k.y = a.y.p;
     k.H = a.x.h; k.W = a.x.w; k.Cin = a.x.c; k.ldx = a.x.ld;
@@ -209,25 +306,75 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
     k.M = (int)a.y.pixels();
     k.act = a.act; k.res_mode = a.res.p ? a.res_mode : RES_NONE;
     if (a.x.c % 4 || a.x.ld % 4 || ((uintptr_t)a.x.p & 15)) fail("conv: input channels/stride must be multiples of 4 (got c=%d ld=%d)", a.x.c, a.x.ld);
-    if (a.kpad % BK || a.kpad < k.K) fail("conv: bad kpad %d for K=%d", a.kpad, k.K);
+    if (a.kpad % KALIGN || a.kpad < k.K) fail("conv: bad kpad %d for K=%d", a.kpad, k.K);
     if ((size_t)a.x.n * a.x.h * a.x.w * a.x.ld >= (1ull << 31)) fail("conv: input tensor too large for 32-bit indexing");
-    // tile choice: widest N tile that the layer fills; fall back to smaller M tiles when the grid
-    // would leave most of the 256 CUs idle
-    const int M = k.M, N = k.Cout;
-    auto blocks = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    if (N <= 32) {
-        launch_cfg<128, 32, 4, 1>(k, s);
-        return 3;
-    }
-    if (N <= 64) {
-        if (blocks(128, 64) >= 256) { launch_cfg<128, 64, 2, 2>(k, s); return 1; }
-        launch_cfg<64, 64, 2, 2>(k, s);
-        return 2;
-    }
-    if (blocks(128, 128) >= 384) { launch_cfg<128, 128, 2, 2>(k, s); return 0; }
-    if (blocks(128, 64) >= 384) { launch_cfg<128, 64, 2, 2>(k, s); return 1; }
-    launch_cfg<64, 64, 2, 2>(k, s);
+    return k;
+}
+
+// default tile choice when no measured choice is supplied: widest tile whose grid still fills the chip
+int conv_default_variant(const ConvArgs &a) {
+    const long M = (long)a.y.pixels(), N = a.y.c;
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    if (N <= 32) return 3;
+    if (N <= 64) return blocks(128, 64) >= 256 ? 1 : 2;
+    if (blocks(128, 128) >= 384) return 0;
+    if (blocks(128, 64) >= 384) return 1;
     return 2;
+}
+
+int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
+    ConvKernelArgs k = make_args(a);
+    if (variant < 0 || variant >= kConvVariants) variant = conv_default_variant(a);
+    static const int abl = getenv("YDS_CONV_ABL") ? atoi(getenv("YDS_CONV_ABL")) : 0;
+    if (abl && variant == 0 && k.act == ACT_LEAKY && k.res_mode == RES_NONE) {
+        switch (abl) {
+            case 1: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 1>(k, s); return 0;
+            case 2: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 2>(k, s); return 0;
+            case 3: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 3>(k, s); return 0;
+            case 7: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 7>(k, s); return 0;
+            case 8: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 8>(k, s); return 0;
+            default: break;
+        }
+    }
+    switch (variant) {
+        case 0: launch_cfg<128, 128, 2, 2, 32>(k, s); break;
+        case 1: launch_cfg<128, 64, 2, 2, 32>(k, s); break;
+        case 2: launch_cfg<64, 64, 2, 2, 32>(k, s); break;
+        case 3: launch_cfg<128, 32, 4, 1, 32>(k, s); break;
+        case 4: launch_cfg<128, 128, 2, 2, 16>(k, s); break;
+        case 5: launch_cfg<128, 64, 2, 2, 16>(k, s); break;
+        default: launch_cfg<64, 128, 2, 2, 16>(k, s); break;
+    }
+    return variant;
+}
+
+// Measured tile choice: times every instantiation on the real buffers (HIP events, median of 3) and returns the
+// fastest.  Wave quantisation on 256 CUs makes the best tile shape a function of (M, N, K, batch) that a closed
+// form predicts poorly, and the measurement costs a few milliseconds per layer at plan time.
+int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
+    hipEvent_t e0, e1;
+    YDS_HIP(hipEventCreate(&e0));
+    YDS_HIP(hipEventCreate(&e1));
+    int best = -1;
+    float best_t = 0.f;
+    for (int v = 0; v < kConvVariants; ++v) {
+        if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
+        launch_conv(a, s, v);
+        float t[3];
+        for (int r = 0; r < 3; ++r) {
+            YDS_HIP(hipEventRecord(e0, s));
+            launch_conv(a, s, v);
+            YDS_HIP(hipEventRecord(e1, s));
+            YDS_HIP(hipEventSynchronize(e1));
+            YDS_HIP(hipEventElapsedTime(&t[r], e0, e1));
+        }
+        float med = t[0] + t[1] + t[2] - fminf(t[0], fminf(t[1], t[2])) - fmaxf(t[0], fmaxf(t[1], t[2]));
+        if (best < 0 || med < best_t) { best = v; best_t = med; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (best_us) *best_us = best_t * 1e3f;
+    return best;
 }
 
 }  // namespace yds

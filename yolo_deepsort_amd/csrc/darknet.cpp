@@ -11,6 +11,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <sstream>
@@ -329,21 +330,38 @@ void Darknet::load_weights(const void *blob, size_t nbytes, int cutoff) {
 }
 
 // --------------------------------------------------------------------------------------- forward
+ConvArgs Darknet::conv_args(int i, int batch) const {
+    const Layer &l = layers[i];
+    ConvArgs a;
+    a.x = l.src < 0 ? input_view(batch) : view(l.src, batch);
+    a.y = view(i, batch);
+    a.w = l.wt.p; a.bias = l.bias.p;
+    a.ksize = l.ksize; a.stride = l.stride; a.pad = l.pad; a.kpad = l.kpad;
+    a.act = l.act;
+    if (l.fused_res >= 0) { a.res = view(l.fused_res, batch); a.res_mode = RES_AFTER_ACT; }
+    return a;
+}
+
+void Darknet::autotune(int batch) {
+    static const bool off = getenv("YDS_NO_AUTOTUNE") != nullptr;
+    for (int i = 0; i < (int)layers.size(); ++i) {
+        Layer &l = layers[i];
+        if (l.type != "convolutional" || !l.loaded || l.tuned_batch == batch) continue;
+        l.variant = off ? -1 : conv_autotune(conv_args(i, batch), stream, nullptr);
+        l.tuned_batch = batch;
+    }
+}
+
 void Darknet::run_graph(int batch) {
     if (batch < 1 || batch > batch_max) fail("forward: batch %d outside [1,%d]", batch, batch_max);
+    autotune(batch);
     for (int i = 0; i < (int)layers.size(); ++i) {
         Layer &l = layers[i];
         if (l.type == "convolutional") {
             if (!l.loaded) fail("forward: layer %d has no weights (call load_darknet_weights)", i);
-            ConvArgs a;
-            a.x = l.src < 0 ? input_view(batch) : view(l.src, batch);
-            a.y = view(i, batch);
-            a.w = l.wt.p; a.bias = l.bias.p;
-            a.ksize = l.ksize; a.stride = l.stride; a.pad = l.pad; a.kpad = l.kpad;
-            a.act = l.act;
-            if (l.fused_res >= 0) { a.res = view(l.fused_res, batch); a.res_mode = RES_AFTER_ACT; }
+            ConvArgs a = conv_args(i, batch);
             if (time_convs) YDS_HIP(hipEventRecord(ev0, stream));
-            int variant = launch_conv(a, stream);
+            int variant = launch_conv(a, stream, l.variant);
             if (time_convs) {
                 YDS_HIP(hipEventRecord(ev1, stream));
                 YDS_HIP(hipEventSynchronize(ev1));
@@ -551,6 +569,43 @@ int yds_conv_timing(yds_net *n, int mode, double *total_us4, int64_t *launches4,
     YDS_API_END
 }
 const char *yds_conv_variant_name(int v) { return yds::conv_variant_name(v); }
+int yds_conv_num_variants(void) { return yds::kConvVariants; }
+int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual, int iters, double *avg_us,
+                   int *variant) {
+    YDS_API_BEGIN
+    using namespace yds;
+    const int pad = (ksize - 1) / 2, ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    const int kpad = (ksize * ksize * cin + 31) / 32 * 32, ldy = (cout + 3) / 4 * 4;
+    std::vector<float> hx((size_t)n * h * w * cin), hw((size_t)cout * kpad), hb(cout);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.f - 1.f; };
+    for (auto &v : hx) v = rnd();
+    for (auto &v : hw) v = rnd() * 0.05f;
+    for (auto &v : hb) v = rnd();
+    DevBuf<float> x, wt, b, y((size_t)n * ho * wo * ldy), r((size_t)n * ho * wo * ldy);
+    x.upload(hx.data(), hx.size()); wt.upload(hw.data(), hw.size()); b.upload(hb.data(), hb.size());
+    YDS_HIP(hipMemset(r.p, 0, r.n * sizeof(float)));
+    ConvArgs a;
+    a.x = View{x.p, n, h, w, cin, cin};
+    a.y = View{y.p, n, ho, wo, cout, ldy};
+    a.w = wt.p; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
+    if (with_residual) { a.res = View{r.p, n, ho, wo, cout, ldy}; a.res_mode = RES_AFTER_ACT; }
+    hipStream_t st;
+    YDS_HIP(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    YDS_HIP(hipEventCreate(&e0)); YDS_HIP(hipEventCreate(&e1));
+    int tuned = getenv("YDS_NO_AUTOTUNE") ? -1 : conv_autotune(a, st, nullptr);
+    for (int i = 0; i < 3; ++i) *variant = launch_conv(a, st, tuned);
+    YDS_HIP(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch_conv(a, st, tuned);
+    YDS_HIP(hipEventRecord(e1, st));
+    YDS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    YDS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1e3 / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+    YDS_API_END
+}
 int yds_darknet_load_injection_sets(yds_net *n, const float *rows_host, const int32_t *offsets_host, int n_sets, float logit) {
     YDS_API_BEGIN
     n->d->load_injection_sets(rows_host, offsets_host, n_sets, logit);

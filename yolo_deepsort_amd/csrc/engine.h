@@ -27,6 +27,7 @@ struct Layer {
     // conv
     int bn = 0, ksize = 1, stride = 1, pad = 0, cin = 0, cin_file = 0, kpad = 0, act = ACT_LINEAR;
     int fused_res = -1;                   // residual layer absorbed from the following shortcut
+    int variant = -1, tuned_batch = 0;    // measured conv tile variant and the batch it was measured at
     bool loaded = false;
     DevBuf<float> wt, bias;
     // shortcut / route / pool
@@ -59,9 +60,11 @@ public:
     void load_injection_sets(const float *rows, const int *offsets, int n_sets, float logit);
     void select_injection_set(int set);
     void enable_conv_timing(bool on);
+    void autotune(int batch);                // measure the fastest conv tile per layer at this batch size
     int64_t flops_per_image() const;
     size_t weight_floats() const;
     View view(int layer, int batch) const;
+    ConvArgs conv_args(int layer, int batch) const;
     View input_view(int batch) const;
 
     int img_h, img_w, batch_max, in_channels = 3;
@@ -86,8 +89,8 @@ public:
     // conv timing (HIP events on this stream)
     bool time_convs = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double conv_us[kConvVariants] = {0, 0, 0, 0}, conv_flops_acc[kConvVariants] = {0, 0, 0, 0};
-    int64_t conv_launches[kConvVariants] = {0, 0, 0, 0};
+    double conv_us[kConvVariants] = {}, conv_flops_acc[kConvVariants] = {};
+    int64_t conv_launches[kConvVariants] = {};
 
 private:
     void run_graph(int batch);
@@ -98,6 +101,13 @@ private:
 class NmsWorkspace {
 public:
     explicit NmsWorkspace(int max_candidates = 16384);
+    ~NmsWorkspace();
+    NmsWorkspace(const NmsWorkspace &) = delete;
+    // asynchronous form: launch() enqueues the kernels and the copies into pinned host memory, collect() reads
+    // them after the caller synchronised the stream
+    void launch(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy, int cap,
+                hipStream_t s);
+    int collect(float *out6_host, int cap);
     // returns number of rows written to out6_host (<= cap); rows sorted by score, boxes in model pixels
     // scaled by (sx, sy) when scale is requested (resize_boxes).
     int run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
@@ -110,6 +120,8 @@ public:
     DevBuf<unsigned long long> mask;   // [max_cand, max_cand/64] suppression bits
     DevBuf<float> kept;          // [300, 6]
     DevBuf<int> order;
+    int *h_counts = nullptr;     // pinned
+    float *h_kept = nullptr;     // pinned [300,6]
 };
 
 // --------------------------------------------------------------------------------------------- ReID
@@ -120,6 +132,8 @@ public:
     void load_tensor(const std::string &name, const float *data, const int64_t *shape, int ndim);
     void finalize();
     void embed_dev(const uint8_t *frame_dev, int h, int w, const float *tlwh_host, int D, float *out_host);
+    // crops of several frames in one batch: frame_of[d] selects frames_dev + frame_of[d]*h*w*3; asynchronous
+    void embed_multi_dev(const uint8_t *frames_dev, int h, int w, const float *tlwh_host, const int *frame_of, int D);
     void embed_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *out_host);
     void preprocess_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *nchw_host);
     void forward_f32_host(const float *nchw, int D, float *out_host);
@@ -139,6 +153,8 @@ public:
     DevBuf<float> in, feat, stage_f32;
     DevBuf<uint8_t> stage_u8;
     DevBuf<int> boxes_dev;
+    std::vector<int> boxes_host;
+    std::map<std::pair<int, int>, int> tuned;   // (conv index, ceil(D/16)) -> measured tile variant
     hipStream_t stream = nullptr;
     double conv_flops_last = 0;
 };

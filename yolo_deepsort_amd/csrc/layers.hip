@@ -294,14 +294,15 @@ void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y,
     YDS_HIP(hipGetLastError());
 }
 
-__global__ void crop_resize_kernel(const uint8_t *frame, int H, int W, const int *boxes, int D, float *y, int Ho, int Wo) {
+__global__ void crop_resize_kernel(const uint8_t *frames, int H, int W, const int *boxes, int D, float *y, int Ho, int Wo) {
     const size_t total = (size_t)D * Ho * Wo;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int ox = idx % Wo;
         size_t t = idx / Wo;
         int oy = t % Ho;
         int d = t / Ho;
-        int x1 = boxes[d * 4], y1 = boxes[d * 4 + 1], cw = boxes[d * 4 + 2] - x1, ch = boxes[d * 4 + 3] - y1;
+        int x1 = boxes[d * 5], y1 = boxes[d * 5 + 1], cw = boxes[d * 5 + 2] - x1, ch = boxes[d * 5 + 3] - y1;
+        const uint8_t *frame = frames + (size_t)boxes[d * 5 + 4] * H * W * 3;
         Tap tx = axis_tap(ox, __fdiv_rn((float)cw, (float)Wo), cw), ty = axis_tap(oy, __fdiv_rn((float)ch, (float)Ho), ch);
         const uint8_t *r0 = frame + ((size_t)(y1 + ty.i0) * W + x1) * 3, *r1 = frame + ((size_t)(y1 + ty.i1) * W + x1) * 3;
         const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
@@ -316,7 +317,7 @@ __global__ void crop_resize_kernel(const uint8_t *frame, int H, int W, const int
     }
 }
 
-void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyxy_dev, int D, const View &y, hipStream_t s) {
+void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyxy_dev, int D, const View &y, hipStream_t s) {   // boxes: [D,5]
     if (D == 0) return;
     hipLaunchKernelGGL(crop_resize_kernel, dim3(grid_for((size_t)D * y.h * y.w)), dim3(256), 0, s, frame, h, w, boxes_xyxy_dev, D, y.p,
                        y.h, y.w);

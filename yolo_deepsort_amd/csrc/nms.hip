@@ -17,6 +17,8 @@
 // rounding (no FMA contraction) so that threshold decisions match.
 #include "engine.h"
 
+#include <string.h>
+
 namespace yds {
 
 constexpr int MAX_DET = 300;
@@ -180,10 +182,17 @@ NmsWorkspace::NmsWorkspace(int max_candidates) : max_cand(max_candidates) {
     counts.alloc(4);
     mask.alloc((size_t)max_cand * (max_cand / 64));
     kept.alloc((size_t)MAX_DET * 6);
+    YDS_HIP(hipHostMalloc((void **)&h_counts, 4 * sizeof(int)));
+    YDS_HIP(hipHostMalloc((void **)&h_kept, (size_t)MAX_DET * 6 * sizeof(float)));
 }
 
-int NmsWorkspace::run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
-                      float *out6_host, int cap, hipStream_t s) {
+NmsWorkspace::~NmsWorkspace() {
+    if (h_counts) (void)hipHostFree(h_counts);
+    if (h_kept) (void)hipHostFree(h_kept);
+}
+
+void NmsWorkspace::launch(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy, int cap,
+                          hipStream_t s) {
     if (attrs < 6) fail("nms: predictions need at least one class");
     box_count.ensure(n_boxes);
     const int nb = (n_boxes + 255) / 256;
@@ -196,16 +205,23 @@ int NmsWorkspace::run(const float *pred_dev, int n_boxes, int attrs, float conf_
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), words_ld * sizeof(unsigned long long), s, sorted.p, mask.p, words_ld, counts.p,
                        max_cand, sx, sy, kept.p, cap);
     YDS_HIP(hipGetLastError());
-    int h_counts[2] = {0, 0};
-    YDS_HIP(hipMemcpyAsync(h_counts, counts.p, sizeof h_counts, hipMemcpyDeviceToHost, s));
-    YDS_HIP(hipStreamSynchronize(s));
+    // results land in pinned host memory; the caller synchronises the stream (or an event) before collect()
+    YDS_HIP(hipMemcpyAsync(h_counts, counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipMemcpyAsync(h_kept, kept.p, (size_t)MAX_DET * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+}
+
+int NmsWorkspace::collect(float *out6_host, int cap) {
     if (h_counts[0] > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (raise conf_thres)", h_counts[0], max_cand);
-    int n = h_counts[1];
-    if (n > 0) {
-        YDS_HIP(hipMemcpyAsync(out6_host, kept.p, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
-        YDS_HIP(hipStreamSynchronize(s));
-    }
+    int n = h_counts[1] < cap ? h_counts[1] : cap;
+    if (n > 0) memcpy(out6_host, h_kept, (size_t)n * 6 * sizeof(float));
     return n;
+}
+
+int NmsWorkspace::run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
+                      float *out6_host, int cap, hipStream_t s) {
+    launch(pred_dev, n_boxes, attrs, conf_thres, iou_thres, sx, sy, cap, s);
+    YDS_HIP(hipStreamSynchronize(s));
+    return collect(out6_host, cap);
 }
 
 }  // namespace yds

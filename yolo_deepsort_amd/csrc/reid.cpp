@@ -10,6 +10,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace yds {
@@ -121,7 +122,12 @@ void ReidNet::forward(int D) {
         a.x = x; a.y = y; a.w = c.wt.p; a.bias = c.bias.p;
         a.ksize = c.k; a.stride = c.stride; a.pad = c.pad; a.kpad = c.kpad; a.act = act;
         if (res) { a.res = *res; a.res_mode = res_mode; }
-        (void)launch_conv(a, stream);
+        // measured tile choice per (layer, crop-count bucket of 16): the batch size varies from call to call
+        const int bucket = (D + 15) / 16;
+        auto key = std::make_pair(ci, bucket);
+        auto it = tuned.find(key);
+        if (it == tuned.end()) it = tuned.emplace(key, getenv("YDS_NO_AUTOTUNE") ? -1 : conv_autotune(a, stream, nullptr)).first;
+        (void)launch_conv(a, stream, it->second);
         conv_flops_last += conv_flops(a);
     };
     View x0 = mk(in, CROP_H, CROP_W, 4);
@@ -151,8 +157,8 @@ void ReidNet::forward(int D) {
     launch_avgpool_l2norm(cur, feat.p, stream);
 }
 
-static void crop_boxes_host(const float *tlwh, int D, int H, int W, std::vector<int> &out) {
-    out.resize((size_t)D * 4);
+static void crop_boxes_host(const float *tlwh, int D, int H, int W, std::vector<int> &out, const int *frame_of = nullptr) {
+    out.resize((size_t)D * 5);
     for (int d = 0; d < D; ++d) {
         float x = tlwh[d * 4], y = tlwh[d * 4 + 1], w = tlwh[d * 4 + 2], h = tlwh[d * 4 + 3];
         float xe = x + w, ye = y + h;                         // fp32 sums like the reference's tensor ops
@@ -161,7 +167,7 @@ static void crop_boxes_host(const float *tlwh, int D, int H, int W, std::vector<
         int x2 = (int)xe < W - 1 ? (int)xe : W - 1;
         int y2 = (int)ye < H - 1 ? (int)ye : H - 1;
         if (x2 <= x1 || y2 <= y1) fail("reid: detection %d yields an empty crop (%d,%d,%d,%d); cv2.resize raises in the reference", d, x1, y1, x2, y2);
-        out[d * 4] = x1; out[d * 4 + 1] = y1; out[d * 4 + 2] = x2; out[d * 4 + 3] = y2;
+        out[d * 5] = x1; out[d * 5 + 1] = y1; out[d * 5 + 2] = x2; out[d * 5 + 3] = y2; out[d * 5 + 4] = frame_of ? frame_of[d] : 0;
     }
 }
 
@@ -180,6 +186,17 @@ void ReidNet::embed_dev(const uint8_t *frame_dev, int h, int w, const float *tlw
         YDS_HIP(hipMemcpyAsync(out_host, feat.p, (size_t)D * EMB * sizeof(float), hipMemcpyDeviceToHost, stream));
         YDS_HIP(hipStreamSynchronize(stream));
     }
+}
+
+void ReidNet::embed_multi_dev(const uint8_t *frames_dev, int h, int w, const float *tlwh_host, const int *frame_of, int D) {
+    if (D == 0) return;
+    if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
+    if (D > max_crops) fail("reid: %d crops exceed max_crops=%d", D, max_crops);
+    crop_boxes_host(tlwh_host, D, h, w, boxes_host, frame_of);
+    boxes_dev.upload(boxes_host.data(), boxes_host.size(), stream);      // boxes_host outlives the copy (member)
+    View x0; x0.p = in.p; x0.n = D; x0.h = CROP_H; x0.w = CROP_W; x0.c = 4; x0.ld = 4;
+    launch_crop_resize(frames_dev, h, w, boxes_dev.p, D, x0, stream);
+    forward(D);
 }
 
 void ReidNet::embed_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *out_host) {

@@ -18,18 +18,22 @@ class Pipeline:
                                                                  conf_thres, nms_thres,
                                                                  _lib.ptr(mask) if mask.size else None, int(mask.size)))
 
-    def step(self, frames_dev, h, w, batch):
-        """frames_dev: device pointer to uint8 [batch,h,w,3].  Returns list of int32 [m,6] (or None when the
-        detector found nothing and the tracker was not called)."""
+    def step(self, frames_dev, h, w, batch, next_frames_dev=None, select_next=None):
+        """frames_dev: device pointer to uint8 [batch,h,w,3]; next_frames_dev (optional): the frames of the next
+        call, whose detector pass is enqueued early.  Returns a list of int32 [m,6] (None when the detector found
+        nothing and the tracker was not called)."""
         out = np.zeros((batch, self.cap, 6), np.int32)
         counts = np.zeros(batch, np.int32)
-        _lib.check(_lib.load().yds_pipeline_step(self._h, frames_dev, h, w, batch, _lib.ptr(out), self.cap, _lib.ptr(counts)))
+        if select_next is not None:
+            _lib.check(_lib.load().yds_pipeline_set_next_injection(self._h, int(select_next)))
+        _lib.check(_lib.load().yds_pipeline_step(self._h, frames_dev, next_frames_dev, h, w, batch, _lib.ptr(out), self.cap,
+                                                 _lib.ptr(counts)))
         return [None if counts[b] < 0 else out[b, :counts[b]].copy() for b in range(batch)]
 
     def stage_us(self):
         us = np.zeros(5, np.float32)
         _lib.check(_lib.load().yds_pipeline_stage_us(self._h, _lib.ptr(us)))
-        return dict(zip(("resize", "detector", "decode_nms", "reid", "assoc"), us.tolist()))
+        return dict(zip(("resize_dev", "detector_dev", "wait_nms_host", "reid_host", "assoc_host"), us.tolist()))
 
     def __del__(self):
         try:
@@ -43,11 +47,12 @@ class Pipeline:
 def conv_timing(net, mode=0):
     """Per tile-variant (total_us, launches, flops, name) of the conv kernel; mode 1 resets+starts, 2 stops."""
     lib = _lib.load()
-    us = (C.c_double * 4)()
-    n = (C.c_int64 * 4)()
-    fl = (C.c_double * 4)()
+    nv = lib.yds_conv_num_variants()
+    us = (C.c_double * nv)()
+    n = (C.c_int64 * nv)()
+    fl = (C.c_double * nv)()
     _lib.check(lib.yds_conv_timing(net._h, mode, us, n, fl))
-    return [dict(name=lib.yds_conv_variant_name(v).decode(), us=us[v], launches=n[v], flops=fl[v]) for v in range(4)]
+    return [dict(name=lib.yds_conv_variant_name(v).decode(), us=us[v], launches=n[v], flops=fl[v]) for v in range(nv)]
 
 
 def load_injection_sets(net, sets, logit=6.0):
