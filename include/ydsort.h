@@ -167,6 +167,11 @@ int yds_pipeline_stage_us(yds_pipe *, float *us5);
  * launch on the handle's stream.  mode 1 = zero the counters and start timing, 2 = stop, 0 = read. */
 int yds_conv_timing(yds_net *, int mode, double *total_us, int64_t *launches, double *flops);
 int yds_conv_num_variants(void);
+/* Arithmetic of the conv kernels: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3, a two-term fp16
+ * split of both operands on v_mfma_f32_32x32x16_f16 with fp32 accumulation (fp32-class accuracy, ~1e-6
+ * relative).  Default 1; env YDS_CONV_MATH=f32|f16x3 overrides the default. */
+int yds_set_conv_math(int mode);
+int yds_get_conv_math(void);
 const char *yds_conv_variant_name(int variant);
 /* Kernel tuning aid: time `iters` launches of one conv layer on random data (HIP events); returns the
  * average launch duration in us and the tile variant that was picked. */

@@ -54,6 +54,8 @@ SIGNATURES = {
     "yds_darknet_select_injection_set": (_I, [_P, _I]),
     "yds_conv_variant_name": (C.c_char_p, [_I]),
     "yds_conv_num_variants": (_I, []),
+    "yds_set_conv_math": (_I, [_I]),
+    "yds_get_conv_math": (_I, []),
     "yds_conv_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "yds_nms": (_I, [_P, _I, _F, _F, _I, _I, _P, _I, _P]),
     "yds_nms_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),

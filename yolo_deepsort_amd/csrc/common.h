@@ -84,6 +84,7 @@ enum ResMode { RES_NONE = 0, RES_AFTER_ACT = 1, RES_BEFORE_ACT = 2 };
 struct ConvArgs {
     View x, y;
     const float *w = nullptr, *bias = nullptr;
+    const void *w16 = nullptr;   // same weights pre-split for the f16x3 kernel: [cout][kpad/32][32 hi | 32 lo] fp16
     View res;              // optional residual (same n,h,w,c as y)
     int ksize = 1, stride = 1, pad = 0, kpad = 0;
     int act = ACT_LINEAR, res_mode = RES_NONE;
@@ -92,7 +93,11 @@ struct ConvArgs {
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice
 int conv_default_variant(const ConvArgs &a);
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us);   // measured fastest variant
-constexpr int kConvVariants = 7;
+constexpr int kF32Variants = 7, kConvVariants = 11;      // ids 0-6: fp32 MFMA tiles, 7-10: f16x3 tiles
+enum ConvMath { MATH_F32 = 0, MATH_F16X3 = 1 };
+int conv_math();                 // process-wide arithmetic mode (env YDS_CONV_MATH=f32|f16x3, default f16x3)
+void set_conv_math(int m);
+void pack_weights_f16x3(const float *w, int cout, int kpad, std::vector<uint16_t> &out);
 const char *conv_variant_name(int v);
 double conv_flops(const ConvArgs &a);
 

@@ -14,43 +14,11 @@
 //   MFMAs, MFMA c consuming component c from both operands - the K order inside a step is permuted
 //   identically for A and B, which a dot product does not care about.
 //   Epilogue: bias + activation (+ residual, before or after the activation) and 128-byte row stores.
-#include "common.h"
+#include "conv_common.h"
 
-#include <stdlib.h>
-#include <type_traits>
+#include <string.h>
 
 namespace yds {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct ConvKernelArgs {
-    const float *x, *w, *bias, *res;
-    float *y;
-    int H, W, Cin, ldx;
-    int Ho, Wo, Cout, ldy, ldr;
-    int ksize, stride, pad;
-    int K, Kpad, M;
-    int act, res_mode;
-    // XCD-aware tile map: the 8 XCDs own an xm x xn grid of rectangles of rm x rn tiles (workgroup id % 8 = XCD)
-    int tiles_m, tiles_n, xm, rm, rn;
-};
-
-constexpr int KALIGN = 32;                // weight rows are zero padded to a multiple of this
-#ifndef YDS_STAGGER
-#define YDS_STAGGER 24
-#endif
-constexpr int STAGGER = YDS_STAGGER;     // s_sleep units of 64 clocks
-
-template <int ACT> __device__ __forceinline__ float apply_act(float v) {
-    if (ACT == ACT_LEAKY) return v > 0.f ? v : v * 0.1f;
-    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
-    if (ACT == ACT_MISH) {
-        float sp = v > 20.f ? v : log1pf(expf(v));
-        return v * tanhf(sp);
-    }
-    return v;
-}
 
 // ABL (tuning ablations, compile time): 1 = no global loads in the loop, 2 = no LDS stores / barrier, 4 = no
 // fragment reads from LDS in the loop, 8 = no MFMA.  0 in production.
@@ -71,14 +39,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    // Workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 and every XCD has a private
-    // 4 MiB L2, so each XCD gets a compact rm x rn rectangle of tiles (small A-rows + B-columns footprint per
-    // K step) instead of a stripe through the whole problem.  Placement only affects speed, never results.
     int m0, n0;
     {
-        const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-        const int tm = (xcd % p.xm) * p.rm + idx % p.rm, tn = (xcd / p.xm) * p.rn + idx / p.rm;
-        if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+        int tm, tn;
+        if (!tile_of_block(p, tm, tn)) return;
         m0 = tm * BM;
         n0 = tn * BN;
     }
@@ -214,37 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
         if (kt + 1 < nk) k_step(Set1{}, kt + 1);
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    // ACT / RES are compile-time so the 16 elements of a fragment are straight-line code: residual loads are
-    // issued together, then bias + activation, then the stores.
-    const int col = lane & 31, rsel = (lane >> 5) * 4;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + col;
-        if (n >= p.Cout) continue;
-        const float bias = p.bias[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * (BM / WM) + i * 32 + rsel;
-            float r[16];
-            if (RES != RES_NONE) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2);
-                    r[e] = m < p.M ? p.res[(size_t)m * p.ldr + n] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                float v = acc[i][j][e] + bias;
-                if (RES == RES_BEFORE_ACT) v += r[e];
-                v = apply_act<ACT>(v);
-                if (RES == RES_AFTER_ACT) v += r[e];
-                if (m < p.M) p.y[(size_t)m * p.ldy + n] = v;
-            }
-        }
-    }
+    conv_epilogue<TM, TN, ACT, RES>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES, int ABL = 0> static void launch_inst(ConvKernelArgs k, hipStream_t s) {
@@ -255,34 +189,15 @@ template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES, int ABL = 0>
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    // choose the XCD grid (xm x xn = 8) with the smallest per-K-step footprint (rows*BM + cols*BN) per XCD
-    k.tiles_m = (k.M + BM - 1) / BM;
-    k.tiles_n = (k.Cout + BN - 1) / BN;
-    long best = -1;
-    for (int xm = 1; xm <= 8; xm *= 2) {
-        int xn = 8 / xm;
-        int rm = (k.tiles_m + xm - 1) / xm, rn = (k.tiles_n + xn - 1) / xn;
-        long waste = (long)rm * rn * 8 - (long)k.tiles_m * k.tiles_n;       // idle workgroup slots
-        long cost = ((long)rm * BM + (long)rn * BN) * 64 + waste * (BM + BN);
-        if (best < 0 || cost < best) { best = cost; k.xm = xm; k.rm = rm; k.rn = rn; }
-    }
-    dim3 grid(8 * k.rm * k.rn);
+    dim3 grid(plan_tile_map(k, BM, BN));
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, k);
     YDS_HIP(hipGetLastError());
 }
 
 template <int BM, int BN, int WM, int WN, int BK> static void launch_cfg(const ConvKernelArgs &k, hipStream_t s) {
-    const int key = k.act * 4 + k.res_mode;
-    switch (key) {
-        case ACT_LINEAR * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_LINEAR, RES_NONE>(k, s);
-        case ACT_LEAKY * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_LEAKY, RES_NONE>(k, s);
-        case ACT_LEAKY * 4 + RES_AFTER_ACT: return launch_inst<BM, BN, WM, WN, BK, ACT_LEAKY, RES_AFTER_ACT>(k, s);
-        case ACT_MISH * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_MISH, RES_NONE>(k, s);
-        case ACT_MISH * 4 + RES_AFTER_ACT: return launch_inst<BM, BN, WM, WN, BK, ACT_MISH, RES_AFTER_ACT>(k, s);
-        case ACT_RELU * 4 + RES_NONE: return launch_inst<BM, BN, WM, WN, BK, ACT_RELU, RES_NONE>(k, s);
-        case ACT_RELU * 4 + RES_BEFORE_ACT: return launch_inst<BM, BN, WM, WN, BK, ACT_RELU, RES_BEFORE_ACT>(k, s);
-        default: fail("conv: unsupported activation/residual combination (%d, %d)", k.act, k.res_mode);
-    }
+#define YDS_CALL(A, R) launch_inst<BM, BN, WM, WN, BK, A, R>(k, s)
+    YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
 }
 
 double conv_flops(const ConvArgs &a) {
@@ -290,13 +205,14 @@ double conv_flops(const ConvArgs &a) {
 }
 
 const char *conv_variant_name(int v) {
-    static const char *names[kConvVariants] = {"conv_igemm_f32<128,128,2,2,32>", "conv_igemm_f32<128,64,2,2,32>", "conv_igemm_f32<64,64,2,2,32>",
+    static const char *names[kF32Variants] = {"conv_igemm_f32<128,128,2,2,32>", "conv_igemm_f32<128,64,2,2,32>", "conv_igemm_f32<64,64,2,2,32>",
                                                "conv_igemm_f32<128,32,4,1,32>", "conv_igemm_f32<128,128,2,2,16>", "conv_igemm_f32<128,64,2,2,16>",
                                                "conv_igemm_f32<64,128,2,2,16>"};
-    return v >= 0 && v < kConvVariants ? names[v] : "?";
+    if (v >= kF32Variants) return conv_f16x3_variant_name(v - kF32Variants);
+    return v >= 0 ? names[v] : "?";
 }
 
-static ConvKernelArgs make_args(const ConvArgs &a) {
+ConvKernelArgs make_conv_args(const ConvArgs &a) {
     ConvKernelArgs k;
     k.x = a.x.p; k.w = a.w; k.bias = a.bias; k.res = a.res.p; k.y = a.y.p;
     k.H = a.x.h; k.W = a.x.w; k.Cin = a.x.c; k.ldx = a.x.ld;
@@ -322,9 +238,28 @@ int conv_default_variant(const ConvArgs &a) {
     return 2;
 }
 
+static int g_math = -1;
+int conv_math() {
+    if (g_math < 0) {
+        const char *e = getenv("YDS_CONV_MATH");
+        g_math = (e && !strcmp(e, "f32")) ? MATH_F32 : MATH_F16X3;
+    }
+    return g_math;
+}
+void set_conv_math(int m) { g_math = m == MATH_F32 ? MATH_F32 : MATH_F16X3; }
+
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
-    ConvKernelArgs k = make_args(a);
-    if (variant < 0 || variant >= kConvVariants) variant = conv_default_variant(a);
+    ConvKernelArgs k = make_conv_args(a);
+    if (variant < 0 || variant >= kConvVariants) {
+        variant = conv_default_variant(a);
+        if (conv_math() == MATH_F16X3) variant = kF32Variants + (variant == 0 ? 0 : variant == 1 ? 2 : 3);
+    }
+    if (variant >= kF32Variants) {
+        if (!a.w16) fail("conv: f16x3 variant requested but the layer has no split weights");
+        k.w = reinterpret_cast<const float *>(a.w16);
+        launch_conv_f16x3(k, variant - kF32Variants, s);
+        return variant;
+    }
     static const int abl = getenv("YDS_CONV_ABL") ? atoi(getenv("YDS_CONV_ABL")) : 0;
     if (abl && variant == 0 && k.act == ACT_LEAKY && k.res_mode == RES_NONE) {
         switch (abl) {
@@ -357,7 +292,8 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
     YDS_HIP(hipEventCreate(&e1));
     int best = -1;
     float best_t = 0.f;
-    for (int v = 0; v < kConvVariants; ++v) {
+    const int v_lo = conv_math() == MATH_F16X3 ? kF32Variants : 0, v_hi = conv_math() == MATH_F16X3 ? kConvVariants : kF32Variants;
+    for (int v = v_lo; v < v_hi; ++v) {
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
         launch_conv(a, s, v);
         float t[3];

@@ -322,6 +322,12 @@ void Darknet::load_weights(const void *blob, size_t nbytes, int cutoff) {
                             (float)((double)src[(((size_t)o * ci + c) * k + kh) * k + kw] * scale[o]);
         ptr += (size_t)co * ci * k * k;
         l.wt.upload(packed.data(), packed.size(), stream);
+        {
+            std::vector<uint16_t> split;
+            pack_weights_f16x3(packed.data(), co, l.kpad, split);
+            l.wt16.upload(split.data(), split.size(), stream);
+            YDS_HIP(hipStreamSynchronize(stream));
+        }
         l.bias.upload(bias.data(), bias.size(), stream);
         YDS_HIP(hipStreamSynchronize(stream));
         l.loaded = true;
@@ -335,7 +341,7 @@ ConvArgs Darknet::conv_args(int i, int batch) const {
     ConvArgs a;
     a.x = l.src < 0 ? input_view(batch) : view(l.src, batch);
     a.y = view(i, batch);
-    a.w = l.wt.p; a.bias = l.bias.p;
+    a.w = l.wt.p; a.bias = l.bias.p; a.w16 = l.wt16.p;
     a.ksize = l.ksize; a.stride = l.stride; a.pad = l.pad; a.kpad = l.kpad;
     a.act = l.act;
     if (l.fused_res >= 0) { a.res = view(l.fused_res, batch); a.res_mode = RES_AFTER_ACT; }
@@ -346,9 +352,10 @@ void Darknet::autotune(int batch) {
     static const bool off = getenv("YDS_NO_AUTOTUNE") != nullptr;
     for (int i = 0; i < (int)layers.size(); ++i) {
         Layer &l = layers[i];
-        if (l.type != "convolutional" || !l.loaded || l.tuned_batch == batch) continue;
+        if (l.type != "convolutional" || !l.loaded || (l.tuned_batch == batch && l.tuned_math == conv_math())) continue;
         l.variant = off ? -1 : conv_autotune(conv_args(i, batch), stream, nullptr);
         l.tuned_batch = batch;
+        l.tuned_math = conv_math();
     }
 }
 
@@ -570,6 +577,8 @@ int yds_conv_timing(yds_net *n, int mode, double *total_us4, int64_t *launches4,
 }
 const char *yds_conv_variant_name(int v) { return yds::conv_variant_name(v); }
 int yds_conv_num_variants(void) { return yds::kConvVariants; }
+int yds_set_conv_math(int mode) { yds::set_conv_math(mode); return 0; }
+int yds_get_conv_math(void) { return yds::conv_math(); }
 int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual, int iters, double *avg_us,
                    int *variant) {
     YDS_API_BEGIN
@@ -583,12 +592,19 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     for (auto &v : hw) v = rnd() * 0.05f;
     for (auto &v : hb) v = rnd();
     DevBuf<float> x, wt, b, y((size_t)n * ho * wo * ldy), r((size_t)n * ho * wo * ldy);
+    DevBuf<uint16_t> wt16;
     x.upload(hx.data(), hx.size()); wt.upload(hw.data(), hw.size()); b.upload(hb.data(), hb.size());
+    {
+        std::vector<uint16_t> split;
+        pack_weights_f16x3(hw.data(), cout, kpad, split);
+        wt16.upload(split.data(), split.size());
+        YDS_HIP(hipDeviceSynchronize());
+    }
     YDS_HIP(hipMemset(r.p, 0, r.n * sizeof(float)));
     ConvArgs a;
     a.x = View{x.p, n, h, w, cin, cin};
     a.y = View{y.p, n, ho, wo, cout, ldy};
-    a.w = wt.p; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
+    a.w = wt.p; a.w16 = wt16.p; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
     if (with_residual) { a.res = View{r.p, n, ho, wo, cout, ldy}; a.res_mode = RES_AFTER_ACT; }
     hipStream_t st;
     YDS_HIP(hipStreamCreate(&st));

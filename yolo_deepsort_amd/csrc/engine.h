@@ -27,9 +27,10 @@ struct Layer {
     // conv
     int bn = 0, ksize = 1, stride = 1, pad = 0, cin = 0, cin_file = 0, kpad = 0, act = ACT_LINEAR;
     int fused_res = -1;                   // residual layer absorbed from the following shortcut
-    int variant = -1, tuned_batch = 0;    // measured conv tile variant and the batch it was measured at
+    int variant = -1, tuned_batch = 0, tuned_math = -1;   // measured conv tile variant, the batch and math mode it was measured at
     bool loaded = false;
     DevBuf<float> wt, bias;
+    DevBuf<uint16_t> wt16;                // split-fp16 copy of wt for the f16x3 kernel
     // shortcut / route / pool
     bool fused = false, zero_br = false;
     int groups = 0, group_id = 0;
@@ -143,6 +144,7 @@ public:
     struct ConvW {
         int cin = 0, cin_file = 0, cout = 0, k = 0, stride = 1, pad = 0, kpad = 0;
         DevBuf<float> wt, bias;
+        DevBuf<uint16_t> wt16;
     };
     int max_crops;
     std::map<std::string, std::vector<float>> raw;
@@ -154,7 +156,8 @@ public:
     DevBuf<uint8_t> stage_u8;
     DevBuf<int> boxes_dev;
     std::vector<int> boxes_host;
-    std::map<std::pair<int, int>, int> tuned;   // (conv index, ceil(D/16)) -> measured tile variant
+    std::map<int, std::pair<int, int>> tuned;   // conv index -> (D at measurement, measured tile variant)
+    int tuned_math = -1;
     hipStream_t stream = nullptr;
     double conv_flops_last = 0;
 };

@@ -79,6 +79,12 @@ void ReidNet::finalize() {
                         packed[(size_t)o * c.kpad + (kh * k + kw) * c.cin + ci] = (float)((double)w[(((size_t)o * cin_file + ci) * k + kh) * k + kw] * scale);
         }
         c.wt.upload(packed.data(), packed.size(), stream);
+        {
+            std::vector<uint16_t> split;
+            pack_weights_f16x3(packed.data(), cout, c.kpad, split);
+            c.wt16.upload(split.data(), split.size(), stream);
+            YDS_HIP(hipStreamSynchronize(stream));
+        }
         c.bias.upload(bias.data(), bias.size(), stream);
         YDS_HIP(hipStreamSynchronize(stream));
         convs.push_back(std::move(c));
@@ -119,15 +125,19 @@ void ReidNet::forward(int D) {
     auto run = [&](int ci, const View &x, const View &y, int act, const View *res, int res_mode) {
         const ConvW &c = convs[ci];
         ConvArgs a;
-        a.x = x; a.y = y; a.w = c.wt.p; a.bias = c.bias.p;
+        a.x = x; a.y = y; a.w = c.wt.p; a.w16 = c.wt16.p; a.bias = c.bias.p;
         a.ksize = c.k; a.stride = c.stride; a.pad = c.pad; a.kpad = c.kpad; a.act = act;
         if (res) { a.res = *res; a.res_mode = res_mode; }
-        // measured tile choice per (layer, crop-count bucket of 16): the batch size varies from call to call
-        const int bucket = (D + 15) / 16;
-        auto key = std::make_pair(ci, bucket);
-        auto it = tuned.find(key);
-        if (it == tuned.end()) it = tuned.emplace(key, getenv("YDS_NO_AUTOTUNE") ? -1 : conv_autotune(a, stream, nullptr)).first;
-        (void)launch_conv(a, stream, it->second);
+        // measured tile choice per layer; the crop count varies from call to call, so a measurement is reused
+        // while D stays within a factor of two of the D it was taken at
+        if (tuned_math != conv_math()) { tuned.clear(); tuned_math = conv_math(); }
+        auto it = tuned.find(ci);
+        if (it == tuned.end() || D > 2 * it->second.first || 2 * D < it->second.first) {
+            int v = getenv("YDS_NO_AUTOTUNE") ? -1 : conv_autotune(a, stream, nullptr);
+            tuned[ci] = std::make_pair(D, v);
+            it = tuned.find(ci);
+        }
+        (void)launch_conv(a, stream, it->second.second);
         conv_flops_last += conv_flops(a);
     };
     View x0 = mk(in, CROP_H, CROP_W, 4);
