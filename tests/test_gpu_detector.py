@@ -55,6 +55,27 @@ def test_mini_every_layer_vs_oracle_and_golden():
     _close(out2[1:2], ref.forward(x2[1:2]))
 
 
+def test_both_math_modes_meet_the_tolerance():
+    """f16x3 (default, split-fp16 MFMA) and the exact fp32 MFMA path against the reference's golden vector."""
+    from yolo_deepsort_amd import _lib
+    g = golden("darknet_tiny416_seed0")
+    x = np.random.RandomState(0).rand(1, 3, 416, 416).astype(F32)
+    lib = _lib.load()
+    default = lib.yds_get_conv_math()
+    outs = {}
+    try:
+        for mode in (0, 1):
+            lib.yds_set_conv_math(mode)
+            net, _ = _nets(cfgs.cfg_text("yolov3-tiny"), 416, 0)
+            outs[mode] = net(x)
+            _close(outs[mode], g["out"], msg=f"math mode {mode}")
+    finally:
+        lib.yds_set_conv_math(default)
+    assert default == 1
+    # the two arithmetic paths agree far inside the tolerance
+    _close(outs[1], outs[0], 1e-4, 1e-4)
+
+
 def test_tiny416_golden():
     g = golden("darknet_tiny416_seed0")
     net, _ = _nets(cfgs.cfg_text("yolov3-tiny"), 416, 0)
