@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
         if (kt + 1 < nk) k_step(Set1{}, kt + 1);
     }
 
-    conv_epilogue<TM, TN, ACT, RES>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+    static_assert((BM / WM) * (BN + 4) <= 2 * (BM + BN) * LDS_LD, "epilogue staging must fit the main-loop LDS");
+    conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc, smem, m0, n0, tid);
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES, int ABL = 0> static void launch_inst(ConvKernelArgs k, hipStream_t s) {
@@ -222,6 +223,8 @@ ConvKernelArgs make_conv_args(const ConvArgs &a) {
     k.M = (int)a.y.pixels();
     k.act = a.act; k.res_mode = a.res.p ? a.res_mode : RES_NONE;
     if (a.x.c % 4 || a.x.ld % 4 || ((uintptr_t)a.x.p & 15)) fail("conv: input channels/stride must be multiples of 4 (got c=%d ld=%d)", a.x.c, a.x.ld);
+    if (a.y.ld % 4 || ((uintptr_t)a.y.p & 15)) fail("conv: output view must be 16-byte aligned with ld %% 4 == 0 (ld=%d)", a.y.ld);
+    if (a.res.p && (a.res.ld % 4 || ((uintptr_t)a.res.p & 15))) fail("conv: residual view must be 16-byte aligned with ld %% 4 == 0");
     if (a.kpad % KALIGN || a.kpad < k.K) fail("conv: bad kpad %d for K=%d", a.kpad, k.K);
     if ((size_t)a.x.n * a.x.h * a.x.w * a.x.ld >= (1ull << 31)) fail("conv: input tensor too large for 32-bit indexing");
     return k;

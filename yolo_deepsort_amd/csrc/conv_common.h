@@ -32,8 +32,12 @@ template <int ACT> __device__ __forceinline__ float apply_act(float v) {
     if (ACT == ACT_LEAKY) return v > 0.f ? v : v * 0.1f;
     if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
     if (ACT == ACT_MISH) {
-        float sp = v > 20.f ? v : log1pf(expf(v));
-        return v * tanhf(sp);
+        // x * tanh(softplus(x)) with ONE exponential:  tanh(log(1+e)) = ((1+e)^2 - 1) / ((1+e)^2 + 1) = n / (n + 2),
+        // n = e*(e+2), e = exp(x).  Same threshold as torch's softplus (x > 20 -> softplus(x) = x, tanh = 1).
+        if (v > 20.f) return v;
+        float e = expf(v);
+        float n = e * (e + 2.f);
+        return v * (n / (n + 2.f));
     }
     return v;
 }
@@ -64,38 +68,64 @@ inline int plan_tile_map(ConvKernelArgs &k, int BM, int BN) {
     return 8 * k.rm * k.rn;
 }
 
-// Epilogue over 32x32 MFMA accumulator fragments.  C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-// ACT / RES are compile-time so the 16 elements of a fragment are straight-line code: residual loads are issued
-// together, then bias + activation, then the stores (128-byte row segments).
-template <int TM, int TN, int ACT, int RES>
-__device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], int m_wave, int n_wave, int lane) {
+// Epilogue over 32x32 MFMA accumulator fragments (C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)).
+// The tile is transposed through LDS (the main loop's buffers are free by now) so that global traffic is 16-byte
+// and row contiguous: bias, residual and output move as float4 along the channel axis.  One pass per row of waves
+// keeps the staging area at (BM/WM) x (BN+4) floats, which fits inside every variant's main-loop allocation.
+// ACT / RES are compile-time.
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
+    constexpr int ROWS = BM / WM, LD = BN + 4, C4 = BN / 4;        // staged rows, padded row length, float4 per row
+    constexpr int RSTEP = 256 / C4;                                  // rows covered by one sweep of the 256 threads
+    static_assert(256 % C4 == 0, "tile width must divide the workgroup");
+    const int lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
     const int col = lane & 31, rsel = (lane >> 5) * 4;
+    const int c4 = tid % C4, rr = tid / C4;
+    const int n = n0 + c4 * 4;
+    const bool n_vec = n + 3 < p.Cout;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_vec) bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
+    else {
+        if (n < p.Cout) bias4.x = p.bias[n];
+        if (n + 1 < p.Cout) bias4.y = p.bias[n + 1];
+        if (n + 2 < p.Cout) bias4.z = p.bias[n + 2];
+    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n_wave + j * 32 + col;
-        if (n >= p.Cout) continue;
-        const float bias = p.bias[n];
+    for (int pass = 0; pass < WM; ++pass) {
+        if (wm == pass) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m_wave + i * 32 + rsel;
-            float r[16];
-            if (RES != RES_NONE) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mb + (e & 3) + 8 * (e >> 2);
-                    r[e] = m < p.M ? p.res[(size_t)m * p.ldr + n] : 0.f;
-                }
-            }
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                float v = acc[i][j][e] + bias;
-                if (RES == RES_BEFORE_ACT) v += r[e];
-                v = apply_act<ACT>(v);
-                if (RES == RES_AFTER_ACT) v += r[e];
-                if (m < p.M) p.y[(size_t)m * p.ldy + n] = v;
-            }
+                    for (int e = 0; e < 16; ++e)
+                        stage[(i * 32 + rsel + (e & 3) + 8 * (e >> 2)) * LD + wn * (BN / WN) + j * 32 + col] = acc[i][j][e];
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = rr; r < ROWS; r += RSTEP) {
+            const int m = m0 + pass * ROWS + r;
+            if (m >= p.M || n >= p.Cout) continue;
+            float4 v = *reinterpret_cast<const float4 *>(stage + r * LD + c4 * 4);
+            float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (RES != RES_NONE) {
+                const float *rp = p.res + (size_t)m * p.ldr + n;
+                if (n_vec) res = *reinterpret_cast<const float4 *>(rp);
+                else { res.x = rp[0]; if (n + 1 < p.Cout) res.y = rp[1]; if (n + 2 < p.Cout) res.z = rp[2]; }
+            }
+            float o[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+            const float rs[4] = {res.x, res.y, res.z, res.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (RES == RES_BEFORE_ACT) o[k] += rs[k];
+                o[k] = apply_act<ACT>(o[k]);
+                if (RES == RES_AFTER_ACT) o[k] += rs[k];
+            }
+            float *yp = p.y + (size_t)m * p.ldy + n;
+            if (n_vec) *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
+            else { yp[0] = o[0]; if (n + 1 < p.Cout) yp[1] = o[1]; if (n + 2 < p.Cout) yp[2] = o[2]; }
+        }
+        if (pass + 1 < WM) __syncthreads();
     }
 }
 

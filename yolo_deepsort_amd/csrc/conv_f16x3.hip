@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
-    conv_epilogue<TM, TN, ACT, RES>(p, acc1, m0 + wm * (BM / WM), n0 + wn * (BN / WN), lane);
+    static_assert((BM / WM) * (BN + 4) * 4 <= 2 * (BM + BN) * ROWB, "epilogue staging must fit the main-loop LDS");
+    conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc1, reinterpret_cast<float *>(smem16), m0, n0, tid);
 }
 
 template <int BM, int BN, int ACT, int RES> static void launch_inst16(ConvKernelArgs k, hipStream_t s) {
