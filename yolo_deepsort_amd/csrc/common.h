@@ -73,6 +73,7 @@ template <typename T> struct DevBuf {
 struct View {
     float *p = nullptr;
     int n = 0, h = 0, w = 0, c = 0, ld = 0;
+    int fmt = 0;             // FMT_F32 or FMT_H16 (h16.h); H16 needs c, ld and the channel offset to be multiples of 32
     size_t pixels() const { return (size_t)n * h * w; }
 };
 
@@ -107,7 +108,8 @@ void launch_upsample(const View &x, const View &y, int stride, hipStream_t s);
 void launch_copy(const View &x, const View &y, hipStream_t s);                 // y[..., :c] = x[..., :c]
 void launch_add(const View &a, const View &b, const View &y, hipStream_t s);
 void launch_nchw_to_nhwc(const float *src_nchw, const View &y, int c_src, hipStream_t s);   // pads channels with 0
-void launch_nhwc_to_nchw(const View &x, float *dst_nchw, hipStream_t s);
+void launch_nhwc_to_nchw(const View &x, float *dst_nchw, hipStream_t s);   // decodes H16 views
+void launch_pack_h16(const float *src_f32, const View &y, hipStream_t s);   // fp32 NHWC (ld = c) -> H16 view (tests / tools)
 // yolo decode: head NHWC [n,h,w,A*(5+C)] -> out[n, box_off + a*h*w + y*w + x, 5+C]
 void launch_yolo_decode(const View &head, float *out, int total_boxes, int box_off, int num_classes,
                         const float *anchors_wh /*host, A pairs*/, int A, int img_h, int img_w, hipStream_t s);

@@ -222,6 +222,9 @@ ConvKernelArgs make_conv_args(const ConvArgs &a) {
     k.K = a.ksize * a.ksize * a.x.c; k.Kpad = a.kpad;
     k.M = (int)a.y.pixels();
     k.act = a.act; k.res_mode = a.res.p ? a.res_mode : RES_NONE;
+    k.fmt_x = a.x.fmt; k.fmt_y = a.y.fmt; k.fmt_r = a.res.p ? a.res.fmt : FMT_F32;
+    if (a.x.fmt == FMT_H16 && (a.x.c % 32 || a.x.ld % 32 || ((uintptr_t)a.x.p & 127))) fail("conv: H16 input needs 32-channel granularity");
+    if (a.y.fmt == FMT_H16 && (a.y.c % 32 || a.y.ld % 32 || ((uintptr_t)a.y.p & 127))) fail("conv: H16 output needs 32-channel granularity");
     if (a.x.c % 4 || a.x.ld % 4 || ((uintptr_t)a.x.p & 15)) fail("conv: input channels/stride must be multiples of 4 (got c=%d ld=%d)", a.x.c, a.x.ld);
     if (a.y.ld % 4 || ((uintptr_t)a.y.p & 15)) fail("conv: output view must be 16-byte aligned with ld %% 4 == 0 (ld=%d)", a.y.ld);
     if (a.res.p && (a.res.ld % 4 || ((uintptr_t)a.res.p & 15))) fail("conv: residual view must be 16-byte aligned with ld %% 4 == 0");
@@ -257,6 +260,8 @@ int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
         variant = conv_default_variant(a);
         if (conv_math() == MATH_F16X3) variant = kF32Variants + (variant == 0 ? 0 : variant == 1 ? 2 : 3);
     }
+    if (variant < kF32Variants && (k.fmt_x != FMT_F32 || k.fmt_y != FMT_F32 || k.fmt_r != FMT_F32))
+        fail("conv: the fp32 MFMA kernel takes fp32 tensors only");
     if (variant >= kF32Variants) {
         if (!a.w16) fail("conv: f16x3 variant requested but the layer has no split weights");
         k.w = reinterpret_cast<const float *>(a.w16);

@@ -1,6 +1,7 @@
 // Pieces shared by the implicit-GEMM convolution kernels (conv.hip: fp32 MFMA, conv_f16x3.hip: split-fp16 MFMA).
 #pragma once
 #include "common.h"
+#include "h16.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -18,6 +19,7 @@ struct ConvKernelArgs {
     int ksize, stride, pad;
     int K, Kpad, M;
     int act, res_mode;
+    int fmt_x, fmt_y, fmt_r;              // TensorFmt of input, output and residual views
     // XCD-aware tile map: the 8 XCDs own an xm x xn grid of rectangles of rm x rn tiles (workgroup id % 8 = XCD)
     int tiles_m, tiles_n, xm, rm, rn;
 };
@@ -107,23 +109,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&
             const int m = m0 + pass * ROWS + r;
             if (m >= p.M || n >= p.Cout) continue;
             float4 v = *reinterpret_cast<const float4 *>(stage + r * LD + c4 * 4);
-            float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+            float rs[4] = {0.f, 0.f, 0.f, 0.f};
             if (RES != RES_NONE) {
-                const float *rp = p.res + (size_t)m * p.ldr + n;
-                if (n_vec) res = *reinterpret_cast<const float4 *>(rp);
-                else { res.x = rp[0]; if (n + 1 < p.Cout) res.y = rp[1]; if (n + 2 < p.Cout) res.z = rp[2]; }
+                const float *rp = p.res + (size_t)m * p.ldr;
+                if (p.fmt_r == FMT_H16) h16_load4(rp, n, rs);                  // H16 tensors have Cout % 32 == 0
+                else if (n_vec) { float4 t = *reinterpret_cast<const float4 *>(rp + n); rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
+                else { rs[0] = rp[n]; if (n + 1 < p.Cout) rs[1] = rp[n + 1]; if (n + 2 < p.Cout) rs[2] = rp[n + 2]; }
             }
             float o[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
-            const float rs[4] = {res.x, res.y, res.z, res.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (RES == RES_BEFORE_ACT) o[k] += rs[k];
                 o[k] = apply_act<ACT>(o[k]);
                 if (RES == RES_AFTER_ACT) o[k] += rs[k];
             }
-            float *yp = p.y + (size_t)m * p.ldy + n;
-            if (n_vec) *reinterpret_cast<float4 *>(yp) = make_float4(o[0], o[1], o[2], o[3]);
-            else { yp[0] = o[0]; if (n + 1 < p.Cout) yp[1] = o[1]; if (n + 2 < p.Cout) yp[2] = o[2]; }
+            float *yp = p.y + (size_t)m * p.ldy;
+            if (p.fmt_y == FMT_H16) h16_store4(yp, n, o);
+            else if (n_vec) *reinterpret_cast<float4 *>(yp + n) = make_float4(o[0], o[1], o[2], o[3]);
+            else { yp[n] = o[0]; if (n + 1 < p.Cout) yp[n + 1] = o[1]; if (n + 2 < p.Cout) yp[n + 2] = o[2]; }
         }
         if (pass + 1 < WM) __syncthreads();
     }

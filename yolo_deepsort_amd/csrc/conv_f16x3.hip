@@ -38,7 +38,9 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
     }
 }
 
-template <int BM, int BN, int ACT, int RES>
+// AIN: format of the input tensor (compile time: the staging differs); output / residual formats are runtime flags
+// of the epilogue.
+template <int BM, int BN, int ACT, int RES, int AIN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -113,11 +115,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
         for (int i = 0; i < A_ROWS; ++i) {
             f32x4 v = a_reg[i];
             if (!((a_ok >> i) & 1u)) v = f32x4{0, 0, 0, 0};
-            h4 hi, lo;
-            split4(v, hi, lo);
-            char *row = a + (r0 + 32 * i) * ROWB + cq * 8;
-            *reinterpret_cast<h4 *>(row) = hi;
-            *reinterpret_cast<h4 *>(row + 64) = lo;
+            if (AIN == FMT_H16) {
+                // pre-split input: chunk cq of the 128-byte group is already [hi | lo] fp16 - plain copy
+                *reinterpret_cast<f32x4 *>(a + (r0 + 32 * i) * ROWB + cq * 16) = v;
+            } else {
+                h4 hi, lo;
+                split4(v, hi, lo);
+                char *row = a + (r0 + 32 * i) * ROWB + cq * 8;
+                *reinterpret_cast<h4 *>(row) = hi;
+                *reinterpret_cast<h4 *>(row + 64) = lo;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) *reinterpret_cast<f32x4 *>(b + (r0 + 32 * i) * ROWB + cq * 16) = b_reg[i];
@@ -181,10 +188,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
     conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc1, reinterpret_cast<float *>(smem16), m0, n0, tid);
 }
 
-template <int BM, int BN, int ACT, int RES> static void launch_inst16(ConvKernelArgs k, hipStream_t s) {
+template <int BM, int BN, int ACT, int RES, int AIN> static void launch_inst16(ConvKernelArgs k, hipStream_t s) {
     constexpr size_t smem = 2ull * (BM + BN) * ROWB;
     static bool attr_set = false;
-    auto kern = conv_igemm_f16x3<BM, BN, ACT, RES>;
+    auto kern = conv_igemm_f16x3<BM, BN, ACT, RES, AIN>;
     if (!attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
@@ -195,9 +202,15 @@ template <int BM, int BN, int ACT, int RES> static void launch_inst16(ConvKernel
 }
 
 template <int BM, int BN> static void launch_cfg16(const ConvKernelArgs &k, hipStream_t s) {
-#define YDS_CALL(A, R) launch_inst16<BM, BN, A, R>(k, s)
-    YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+    if (k.fmt_x == FMT_H16) {
+#define YDS_CALL(A, R) launch_inst16<BM, BN, A, R, FMT_H16>(k, s)
+        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
+    } else {
+#define YDS_CALL(A, R) launch_inst16<BM, BN, A, R, FMT_F32>(k, s)
+        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+    }
 }
 
 const char *conv_f16x3_variant_name(int v) {

@@ -9,6 +9,7 @@
 //     producers write straight into channel slices of the concatenated buffer when possible;
 //   * every layer keeps its own buffer for batch_max images (288 GB of HBM: no reuse games).
 #include "engine.h"
+#include "h16.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -223,12 +224,37 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
         }
         if (l.groups) fail("cfg: grouped multi-source routes are not supported");
     }
+    // ---- pass 4: tensor formats.  In f16x3 mode a buffer is kept pre-split (H16, h16.h) when everything that
+    //      lives in it sits at 32-channel granularity; the image and the 255-channel heads stay fp32.
+    math = conv_math();
+    std::vector<char> h16_ok(L, math == MATH_F16X3 ? 1 : 0);
+    auto owner_of = [&](int j, int &off) {
+        const Layer &l = layers[j];
+        if (l.type == "route" && l.refs.size() > 1) { off = 0; return j; }
+        int r = l.root;
+        if (storage[r].redirected) { off = storage[r].coff + l.coff; return storage[r].into; }
+        off = l.coff;
+        return r;
+    };
+    for (int j = 0; j < L; ++j) {
+        if (layers[j].type == "yolo") continue;
+        int off = 0, o = owner_of(j, off);
+        if (off % 32 || layers[j].c % 32) h16_ok[o] = 0;
+    }
+    // a concatenation fed by copies must share the copied tensors' format: demote both sides to fp32 on mismatch
+    for (int pass = 0; pass < 2; ++pass)
+        for (int i = 0; i < L; ++i)
+            for (auto &cp : layers[i].copies) {
+                int off = 0, o = owner_of(cp.first, off);
+                if (o >= 0 && h16_ok[o] != h16_ok[i]) h16_ok[o] = h16_ok[i] = 0;
+            }
     size_t total_floats = 0;
     for (int i = 0; i < L; ++i) {
         Layer &l = layers[i];
         bool owns = (is_producer(i) && !storage[i].redirected) || (l.type == "route" && l.refs.size() > 1);
         if (!owns) continue;
         if (storage[i].ld == 0) storage[i].ld = (l.c + 3) / 4 * 4;
+        storage[i].fmt = (h16_ok[i] && storage[i].ld % 32 == 0) ? FMT_H16 : FMT_F32;
         size_t n = (size_t)batch_max * l.h * l.w * storage[i].ld;
         storage[i].buf.alloc(n);
         YDS_HIP(hipMemsetAsync(storage[i].buf.p, 0, n * sizeof(float), stream));
@@ -254,7 +280,7 @@ View Darknet::view(int i, int batch) const {
     View v;
     v.n = batch; v.h = l.h; v.w = l.w; v.c = l.c;
     if (l.type == "route" && l.refs.size() > 1) {
-        v.p = storage[i].buf.p; v.ld = storage[i].ld;
+        v.p = storage[i].buf.p; v.ld = storage[i].ld; v.fmt = storage[i].fmt;
         return v;
     }
     const Storage &st = storage[r];
@@ -262,9 +288,11 @@ View Darknet::view(int i, int batch) const {
         const Storage &dst = storage[st.into];
         v.p = dst.buf.p + st.coff + l.coff;
         v.ld = dst.ld;
+        v.fmt = dst.fmt;
     } else {
         v.p = st.buf.p + l.coff;
         v.ld = st.ld;
+        v.fmt = st.fmt;
     }
     return v;
 }
@@ -361,6 +389,7 @@ void Darknet::autotune(int batch) {
 
 void Darknet::run_graph(int batch) {
     if (batch < 1 || batch > batch_max) fail("forward: batch %d outside [1,%d]", batch, batch_max);
+    if (math != conv_math()) fail("forward: this network was planned for conv math %d, current mode is %d (re-create it)", math, conv_math());
     autotune(batch);
     for (int i = 0; i < (int)layers.size(); ++i) {
         Layer &l = layers[i];
@@ -602,10 +631,17 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     }
     YDS_HIP(hipMemset(r.p, 0, r.n * sizeof(float)));
     ConvArgs a;
-    a.x = View{x.p, n, h, w, cin, cin};
-    a.y = View{y.p, n, ho, wo, cout, ldy};
+    const bool f16 = conv_math() == MATH_F16X3;
+    a.x = View{x.p, n, h, w, cin, cin, (f16 && cin % 32 == 0) ? FMT_H16 : FMT_F32};
+    a.y = View{y.p, n, ho, wo, cout, ldy, (f16 && cout % 32 == 0) ? FMT_H16 : FMT_F32};
+    if (a.x.fmt == FMT_H16) {
+        DevBuf<float> raw;
+        raw.upload(hx.data(), hx.size());
+        launch_pack_h16(raw.p, a.x, nullptr);
+        YDS_HIP(hipDeviceSynchronize());
+    }
     a.w = wt.p; a.w16 = wt16.p; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
-    if (with_residual) { a.res = View{r.p, n, ho, wo, cout, ldy}; a.res_mode = RES_AFTER_ACT; }
+    if (with_residual) { a.res = View{r.p, n, ho, wo, cout, ldy, a.y.fmt}; a.res_mode = RES_AFTER_ACT; }
     hipStream_t st;
     YDS_HIP(hipStreamCreate(&st));
     hipEvent_t e0, e1;

@@ -42,6 +42,7 @@ struct Layer {
 struct Storage {
     DevBuf<float> buf;
     int ld = 0;
+    int fmt = 0;                          // TensorFmt of the owned buffer (H16 only in f16x3 mode, 32-channel granularity)
     bool redirected = false;              // producer writes into a slice of storage[into]
     int into = -1, coff = 0;
 };
@@ -69,6 +70,7 @@ public:
     View input_view(int batch) const;
 
     int img_h, img_w, batch_max, in_channels = 3;
+    int math = 0;                            // conv arithmetic the plan (tensor formats) was built for
     int total_boxes = 0, attrs = 0;
     std::vector<Layer> layers;
     std::vector<Storage> storage;

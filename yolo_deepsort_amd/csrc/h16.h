@@ -1,0 +1,63 @@
+// "H16" activation format of the f16x3 convolution path.
+//
+// A tensor whose channel count is a multiple of 32 may be stored pre-split for the split-fp16 MFMA kernel: every
+// pixel keeps, per group of 32 channels, 128 bytes = [32 x hi fp16 | 32 x lo fp16] with
+//     x * 2^-8 = hi + lo * 2^-11        hi = fp16(x * 2^-8),  lo = fp16((x * 2^-8 - hi) * 2^11)
+// i.e. 22 significant bits per value in the same 4 bytes per channel as fp32.  Byte-wise the tensor looks like an
+// fp32 NHWC tensor whose "float slots" [32g, 32g+32) hold group g, so copies, nearest upsampling and channel views
+// at 32-channel granularity are format agnostic.  The conv kernel stages such a tensor into LDS as opaque 16-byte
+// chunks (no conversion arithmetic in the K loop); producers encode in their epilogues.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace yds {
+
+enum TensorFmt { FMT_F32 = 0, FMT_H16 = 1 };
+
+constexpr float H16_A_SCALE = 1.f / 256.f, H16_LO_SCALE = 2048.f;
+
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void h16_encode4(const float v[4], h16x4 &hi, h16x4 &lo) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float xs = v[c] * H16_A_SCALE;
+        _Float16 h = (_Float16)xs;                         // round to nearest even
+        hi[c] = h;
+        lo[c] = (_Float16)((xs - (float)h) * H16_LO_SCALE);
+    }
+}
+
+__device__ __forceinline__ void h16_decode4(const h16x4 &hi, const h16x4 &lo, float v[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = ((float)hi[c] + (float)lo[c] * (1.f / H16_LO_SCALE)) * (1.f / H16_A_SCALE);
+}
+
+// pixel: pointer to the pixel's first float slot; c: channel index, multiple of 4
+__device__ __forceinline__ void h16_load4(const float *pixel, int c, float v[4]) {
+    const char *g = reinterpret_cast<const char *>(pixel + (c & ~31)) + (c & 31) * 2;
+    h16x4 hi = *reinterpret_cast<const h16x4 *>(g), lo = *reinterpret_cast<const h16x4 *>(g + 64);
+    h16_decode4(hi, lo, v);
+}
+__device__ __forceinline__ void h16_store4(float *pixel, int c, const float v[4]) {
+    char *g = reinterpret_cast<char *>(pixel + (c & ~31)) + (c & 31) * 2;
+    h16x4 hi, lo;
+    h16_encode4(v, hi, lo);
+    *reinterpret_cast<h16x4 *>(g) = hi;
+    *reinterpret_cast<h16x4 *>(g + 64) = lo;
+}
+
+// generic 4-channel accessors on a (pointer, fmt) pair
+__device__ __forceinline__ void load4(const float *pixel, int c, int fmt, float v[4]) {
+    if (fmt == FMT_H16) h16_load4(pixel, c, v);
+    else {
+        float4 t = *reinterpret_cast<const float4 *>(pixel + c);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+}
+__device__ __forceinline__ void store4(float *pixel, int c, int fmt, const float v[4]) {
+    if (fmt == FMT_H16) h16_store4(pixel, c, v);
+    else *reinterpret_cast<float4 *>(pixel + c) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+}  // namespace yds

@@ -12,6 +12,7 @@
 // All kernels are one-element(-vector)-per-thread streaming kernels with 16-byte accesses where the
 // layout allows; grids are capped and grid-strided.
 #include "common.h"
+#include "h16.h"
 
 namespace yds {
 
@@ -24,7 +25,7 @@ static inline int grid_for(size_t work, int block = 256) {
 
 // ------------------------------------------------------------------------------------ maxpool
 __global__ void maxpool_kernel(const float *x, float *y, int N, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
-                               int k, int stride, int pad, int zero_br) {
+                               int k, int stride, int pad, int zero_br, int fmt_in, int fmt_out) {
     const int C4 = C >> 2;
     const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -39,17 +40,16 @@ __global__ void maxpool_kernel(const float *x, float *y, int N, int H, int W, in
             int iy = oy * stride - pad + dy;
             for (int dx = 0; dx < k; ++dx) {
                 int ix = ox * stride - pad + dx;
-                float4 v;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    v = *reinterpret_cast<const float4 *>(x + ((size_t)(n * H + iy) * W + ix) * ldx + c4 * 4);
-                else if (zero_br)
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
-                else
+                    load4(x + ((size_t)(n * H + iy) * W + ix) * ldx, c4 * 4, fmt_in, v);
+                else if (!zero_br)
                     continue;
-                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                m.x = fmaxf(m.x, v[0]); m.y = fmaxf(m.y, v[1]); m.z = fmaxf(m.z, v[2]); m.w = fmaxf(m.w, v[3]);
             }
         }
-        *reinterpret_cast<float4 *>(y + pix * ldy + c4 * 4) = m;
+        const float o[4] = {m.x, m.y, m.z, m.w};
+        store4(y + pix * ldy, c4 * 4, fmt_out, o);
     }
 }
 
@@ -57,7 +57,7 @@ void launch_maxpool(const View &x, const View &y, int k, int stride, int pad, bo
     if (x.c % 4 || x.ld % 4 || y.ld % 4) fail("maxpool: channels must be a multiple of 4");
     size_t total = y.pixels() * (x.c / 4);
     hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, s, x.p, y.p, x.n, x.h, x.w, x.c, x.ld, y.h, y.w,
-                       y.ld, k, stride, pad, zero_pad_br ? 1 : 0);
+                       y.ld, k, stride, pad, zero_pad_br ? 1 : 0, x.fmt, y.fmt);
     YDS_HIP(hipGetLastError());
 }
 
@@ -79,6 +79,7 @@ __global__ void upsample_kernel(const float *x, float *y, int N, int H, int W, i
 
 void launch_upsample(const View &x, const View &y, int stride, hipStream_t s) {
     if (x.c % 4 || x.ld % 4 || y.ld % 4) fail("upsample: channels must be a multiple of 4");
+    if (x.fmt != y.fmt) fail("upsample: source and destination formats differ");
     size_t total = y.pixels() * (x.c / 4);
     hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x.p, y.p, x.n, x.h, x.w, x.c, x.ld, y.ld, stride);
     YDS_HIP(hipGetLastError());
@@ -104,6 +105,7 @@ __global__ void copy_scalar_kernel(const float *x, float *y, size_t pixels, int 
 }
 
 void launch_copy(const View &x, const View &y, hipStream_t s) {
+    if (x.fmt != y.fmt) fail("copy: source and destination formats differ");
     bool vec = !(x.c % 4 || x.ld % 4 || y.ld % 4 || ((uintptr_t)x.p & 15) || ((uintptr_t)y.p & 15));
     if (vec)
         hipLaunchKernelGGL(copy_kernel, dim3(grid_for(x.pixels() * (x.c / 4))), dim3(256), 0, s, x.p, y.p, x.pixels(), x.c, x.ld, y.ld);
@@ -112,17 +114,24 @@ void launch_copy(const View &x, const View &y, hipStream_t s) {
     YDS_HIP(hipGetLastError());
 }
 
-__global__ void add_kernel(const float *a, const float *b, float *y, size_t pixels, int C, int lda, int ldb, int ldy) {
-    const size_t total = pixels * C;
+__global__ void add_kernel(const float *a, const float *b, float *y, size_t pixels, int C, int lda, int ldb, int ldy, int fa, int fb, int fy) {
+    const int C4 = C >> 2;
+    const size_t total = pixels * C4;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        int c = idx % C;
-        size_t pix = idx / C;
-        y[pix * ldy + c] = a[pix * lda + c] + b[pix * ldb + c];
+        int c4 = idx % C4;
+        size_t pix = idx / C4;
+        float u[4], v[4];
+        load4(a + pix * lda, c4 * 4, fa, u);
+        load4(b + pix * ldb, c4 * 4, fb, v);
+        const float o[4] = {u[0] + v[0], u[1] + v[1], u[2] + v[2], u[3] + v[3]};
+        store4(y + pix * ldy, c4 * 4, fy, o);
     }
 }
 
 void launch_add(const View &a, const View &b, const View &y, hipStream_t s) {
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(a.pixels() * a.c)), dim3(256), 0, s, a.p, b.p, y.p, a.pixels(), a.c, a.ld, b.ld, y.ld);
+    if (a.c % 4 || a.ld % 4 || b.ld % 4 || y.ld % 4) fail("add: channels must be a multiple of 4");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(a.pixels() * (a.c / 4))), dim3(256), 0, s, a.p, b.p, y.p, a.pixels(), a.c, a.ld, b.ld, y.ld,
+                       a.fmt, b.fmt, y.fmt);
     YDS_HIP(hipGetLastError());
 }
 
@@ -144,7 +153,7 @@ void launch_nchw_to_nhwc(const float *src_nchw, const View &y, int c_src, hipStr
     YDS_HIP(hipGetLastError());
 }
 
-__global__ void nhwc_to_nchw_kernel(const float *x, float *dst, int N, int C, int H, int W, int ldx) {
+__global__ void nhwc_to_nchw_kernel(const float *x, float *dst, int N, int C, int H, int W, int ldx, int fmt) {
     const size_t total = (size_t)N * C * H * W;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int xw = idx % W;
@@ -153,11 +162,35 @@ __global__ void nhwc_to_nchw_kernel(const float *x, float *dst, int N, int C, in
         t /= H;
         int c = t % C;
         int n = t / C;
-        dst[idx] = x[((size_t)(n * H + yh) * W + xw) * ldx + c];
+        const float *pixel = x + ((size_t)(n * H + yh) * W + xw) * ldx;
+        if (fmt == FMT_H16) {
+            float v[4];
+            h16_load4(pixel, c & ~3, v);
+            dst[idx] = v[c & 3];
+        } else {
+            dst[idx] = pixel[c];
+        }
     }
 }
+__global__ void pack_h16_kernel(const float *src, float *y, size_t pixels, int C, int ldy) {
+    const int C4 = C >> 2;
+    const size_t total = pixels * C4;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int c4 = idx % C4;
+        size_t pix = idx / C4;
+        float4 t = *reinterpret_cast<const float4 *>(src + pix * C + c4 * 4);
+        const float v[4] = {t.x, t.y, t.z, t.w};
+        h16_store4(y + pix * ldy, c4 * 4, v);
+    }
+}
+void launch_pack_h16(const float *src_f32, const View &y, hipStream_t s) {
+    if (y.c % 32 || y.ld % 32) fail("pack_h16: channels must be a multiple of 32");
+    hipLaunchKernelGGL(pack_h16_kernel, dim3(grid_for(y.pixels() * (y.c / 4))), dim3(256), 0, s, src_f32, y.p, y.pixels(), y.c, y.ld);
+    YDS_HIP(hipGetLastError());
+}
+
 void launch_nhwc_to_nchw(const View &x, float *dst_nchw, hipStream_t s) {
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(x.pixels() * x.c)), dim3(256), 0, s, x.p, dst_nchw, x.n, x.c, x.h, x.w, x.ld);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(x.pixels() * x.c)), dim3(256), 0, s, x.p, dst_nchw, x.n, x.c, x.h, x.w, x.ld, x.fmt);
     YDS_HIP(hipGetLastError());
 }
 
@@ -325,7 +358,7 @@ void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyx
 }
 
 // ------------------------------------------------------------------------------------ ReID tail
-__global__ void avgpool_l2norm_kernel(const float *x, float *out, int P, int C, int ld) {
+__global__ void avgpool_l2norm_kernel(const float *x, float *out, int P, int C, int ld, int fmt) {
     // one workgroup per crop; C == blockDim.x * 2
     __shared__ float red[8];
     const int d = blockIdx.x;
@@ -334,7 +367,16 @@ __global__ void avgpool_l2norm_kernel(const float *x, float *out, int P, int C, 
     for (int j = 0; j < 2; ++j) {
         int c = threadIdx.x + j * blockDim.x;
         float sum = 0.f;
-        for (int p = 0; p < P; ++p) sum += x[((size_t)d * P + p) * ld + c];
+        for (int p = 0; p < P; ++p) {
+            const float *pixel = x + ((size_t)d * P + p) * ld;
+            if (fmt == FMT_H16) {
+                float q[4];
+                h16_load4(pixel, c & ~3, q);
+                sum += q[c & 3];
+            } else {
+                sum += pixel[c];
+            }
+        }
         v[j] = sum / (float)P;
         ss += v[j] * v[j];
     }
@@ -351,7 +393,7 @@ __global__ void avgpool_l2norm_kernel(const float *x, float *out, int P, int C, 
 void launch_avgpool_l2norm(const View &x, float *out, hipStream_t s) {
     if (x.n == 0) return;
     if (x.c != 512) fail("avgpool: expected 512 channels");
-    hipLaunchKernelGGL(avgpool_l2norm_kernel, dim3(x.n), dim3(256), 0, s, x.p, out, x.h * x.w, x.c, x.ld);
+    hipLaunchKernelGGL(avgpool_l2norm_kernel, dim3(x.n), dim3(256), 0, s, x.p, out, x.h * x.w, x.c, x.ld, x.fmt);
     YDS_HIP(hipGetLastError());
 }
 

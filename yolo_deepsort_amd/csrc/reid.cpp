@@ -8,6 +8,7 @@
 // Crop boxes follow DeepSort._s_tlwh_to_xyxy (deep_sort/deep_sort.py:116-122): python int()
 // truncation of fp32 sums, clipped to [0, W-1] / [0, H-1], end-exclusive slices.
 #include "engine.h"
+#include "h16.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -117,8 +118,10 @@ void ReidNet::finalize() {
 void ReidNet::forward(int D) {
     if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
     if (D < 1 || D > max_crops) fail("reid: %d crops outside [1,%d]", D, max_crops);
+    const bool f16 = conv_math() == MATH_F16X3;
     auto mk = [&](DevBuf<float> &b, int h, int w, int c) {
         View v; v.p = b.p; v.n = D; v.h = h; v.w = w; v.c = c; v.ld = c;
+        v.fmt = (f16 && c % 32 == 0) ? FMT_H16 : FMT_F32;      // activations between the convs stay pre-split
         return v;
     };
     conv_flops_last = 0;
