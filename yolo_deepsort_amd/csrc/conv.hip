@@ -295,6 +295,11 @@ int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
 // fastest.  Wave quantisation on 256 CUs makes the best tile shape a function of (M, N, K, batch) that a closed
 // form predicts poorly, and the measurement costs a few milliseconds per layer at plan time.
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
+    if (const char *f = getenv("YDS_CONV_FORCE")) {      // tuning aid: pin a variant id where it is applicable
+        int v = atoi(f);
+        bool dma = v >= kF32Variants + 4;
+        if (!(dma && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
+    }
     hipEvent_t e0, e1;
     YDS_HIP(hipEventCreate(&e0));
     YDS_HIP(hipEventCreate(&e1));
@@ -303,6 +308,7 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
     const int v_lo = conv_math() == MATH_F16X3 ? kF32Variants : 0, v_hi = conv_math() == MATH_F16X3 ? kConvVariants : kF32Variants;
     for (int v = v_lo; v < v_hi; ++v) {
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
+        if (v >= kF32Variants + 4 && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // LDS-DMA tiles need a pre-split input
         launch_conv(a, s, v);
         float t[3];
         for (int r = 0; r < 3; ++r) {

@@ -148,7 +148,7 @@ ConvKernelArgs make_conv_args(const ConvArgs &a);
     }
 
 // split-fp16 path (conv_f16x3.hip)
-constexpr int kF16Variants = 4;
+constexpr int kF16Variants = 8;            // 0-3 register-staged tiles, 4-7 LDS-DMA ring (pre-split inputs only)
 const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
 

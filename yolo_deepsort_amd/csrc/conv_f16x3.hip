@@ -188,6 +188,189 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
     conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc1, reinterpret_cast<float *>(smem16), m0, n0, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for pre-split (H16) inputs: both operands are opaque 16-byte chunks, so they go global -> LDS with
+// global_load_lds_dwordx4 (no staging VGPRs, no ds_write, no conversion) through an NS-deep ring of K=16 stages.
+// The staged kernel above keeps exactly one tile of loads in flight per workgroup and its K loop runs at the
+// latency of that batch; here NS-1 stages are in flight and the wave only waits (counted vmcnt) for the oldest.
+//   stage  = BM + BN rows of 64 B: [16 hi | 16 lo] fp16 = one MFMA k-step; row r keeps chunk c at position
+//            c ^ ((r >> 2) & 3) (the DMA writes lane-linear, so the swizzle is applied to the SOURCE address and
+//            again by the fragment reads; 16 consecutive rows then hit 16 distinct 16-byte bank slots)
+//   ring   : iteration t waits for tile t (vmcnt = DMAs of the younger tiles), one s_barrier, re-fills the stage
+//            that iteration t-1 finished reading, then 12 MFMAs per wave on stage t % NS
+//   zero padding: out-of-image taps fetch from a 16-byte zero page instead of branching.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int NS, int ACT, int RES>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_dma(ConvKernelArgs p, const void *zero_page) {
+    constexpr int WM = 2, WN = 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int ROW = 64;
+    constexpr int A_BYTES = BM * ROW, STAGE = (BM + BN) * ROW;
+    constexpr int A_INST = BM / 64, B_INST = BN / 64;          // DMA instructions per wave per stage (16 rows each)
+    constexpr int IN = A_INST + B_INST;
+    static_assert(NS >= 3 && NS <= 6, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char ring[];     // [NS][STAGE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int m0, n0;
+    {
+        int tm, tn;
+        if (!tile_of_block(p, tm, tn)) return;
+        m0 = tm * BM;
+        n0 = tn * BN;
+    }
+    // DMA lane roles: instruction q of this wave fills rows (q*4 + wave)*16 .. +15; lane -> (row, position)
+    const int drow = lane >> 2, dpos = lane & 3;
+    int a_base[A_INST], a_iy[A_INST], a_ix[A_INST], a_sc[A_INST];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int q = 0; q < A_INST; ++q) {
+        const int row = (q * 4 + wave) * 16 + drow;
+        a_sc[q] = dpos ^ ((row >> 2) & 3);                      // logical chunk this lane fetches
+        const int m = m0 + row;
+        if (m < p.M) {
+            int img = m / HoWo, rem = m - img * HoWo;
+            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_iy[q] = oy * p.stride - p.pad;
+            a_ix[q] = ox * p.stride - p.pad;
+            a_base[q] = ((img * p.H + a_iy[q]) * p.W + a_ix[q]) * p.ldx;
+        } else {
+            a_iy[q] = -(1 << 28);
+            a_ix[q] = 0;
+            a_base[q] = 0;
+        }
+    }
+    const char *w_row[B_INST];
+    int b_sc[B_INST];
+#pragma unroll
+    for (int q = 0; q < B_INST; ++q) {
+        const int row = (q * 4 + wave) * 16 + drow;
+        b_sc[q] = dpos ^ ((row >> 2) & 3);
+        w_row[q] = reinterpret_cast<const char *>(p.w) + (size_t)min(n0 + row, p.Cout - 1) * p.Kpad * 4;
+    }
+    // byte offset of logical chunk sc (0,1: hi k0-7 / k8-15; 2,3: lo) of half h inside a 128-byte group
+    auto chunk_off = [](int h, int sc) { return (sc < 2 ? 0 : 64) + (2 * h + (sc & 1)) * 16; };
+
+    int kt_issue = 0, kh = 0, kw = 0, kc = 0;                   // next K16 tile to issue and its (tap, channel) position
+    auto issue = [&](int stage) {
+        const int h = (kc >> 4) & 1, gb = kc & ~31;
+        char *sa = ring + stage * STAGE, *sb = sa + A_BYTES;
+        const int tap_off = (kh * p.W + kw) * p.ldx + gb;
+#pragma unroll
+        for (int q = 0; q < A_INST; ++q) {
+            int iy = a_iy[q] + kh, ix = a_ix[q] + kw;
+            bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const char *src = ok ? reinterpret_cast<const char *>(p.x + (a_base[q] + tap_off)) + chunk_off(h, a_sc[q])
+                                 : reinterpret_cast<const char *>(zero_page);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(sa + (q * 4 + wave) * 16 * ROW), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < B_INST; ++q) {
+            const char *src = w_row[q] + (size_t)(kt_issue >> 1) * 128 + chunk_off(kt_issue & 1, b_sc[q]);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(sb + (q * 4 + wave) * 16 * ROW), 16, 0, 0);
+        }
+        ++kt_issue;
+        kc += 16;
+        if (kc >= p.Cin) { kc = 0; if (++kw == p.ksize) { kw = 0; ++kh; } }
+    };
+
+    f32x16 acc1[TM][TN], acc2[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
+
+    const int nk = p.K / 16;                                    // Cin % 32 == 0 on this path
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s);
+
+    // fragment addressing: row = lane & 31 (+ tile offsets, multiples of 32), chunk kb / 2+kb at swizzled position
+    const int swz = (lane >> 2) & 3, kb = lane >> 5;
+    const int a_frag = (wm * (BM / WM) + (lane & 31)) * ROW, b_frag = A_BYTES + (wn * (BN / WN) + (lane & 31)) * ROW;
+    const int pos_hi = (kb ^ swz) * 16, pos_lo = ((2 + kb) ^ swz) * 16;
+
+    for (int t = 0; t < nk; ++t) {
+        // tile t must have landed; the NS-2 younger tiles may stay in flight
+        const int younger = min(NS - 2, nk - 1 - t);
+        switch (younger) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<IN>(); break;
+            case 2: wait_vmcnt<2 * IN>(); break;
+            case 3: wait_vmcnt<3 * IN>(); break;
+            default: wait_vmcnt<4 * IN>(); break;
+        }
+        __builtin_amdgcn_s_barrier();
+        if (t + NS - 1 < nk) issue((t + NS - 1) % NS);
+        const char *st = ring + (t % NS) * STAGE;
+        h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_hi);
+            al[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_lo);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bh[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_hi);
+            bl[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_lo);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
+                acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
+                acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
+            }
+    }
+    __syncthreads();                                            // every wave is done with the ring
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
+    static_assert((BM / WM) * (BN + 4) * 4 <= NS * STAGE, "epilogue staging must fit the ring");
+    conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc1, reinterpret_cast<float *>(ring), m0, n0, tid);
+}
+
+static const void *zero_page_dev() {
+    static void *z = nullptr;
+    if (!z) {
+        YDS_HIP(hipMalloc(&z, 256));
+        YDS_HIP(hipMemset(z, 0, 256));
+    }
+    return z;
+}
+
+template <int BM, int BN, int NS, int ACT, int RES> static void launch_inst_dma(ConvKernelArgs k, hipStream_t s) {
+    constexpr size_t smem = (size_t)NS * (BM + BN) * 64;
+    static bool attr_set = false;
+    auto kern = conv_igemm_f16x3_dma<BM, BN, NS, ACT, RES>;
+    if (!attr_set) {
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid(plan_tile_map(k, BM, BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, k, zero_page_dev());
+    YDS_HIP(hipGetLastError());
+}
+
+template <int BM, int BN, int NS> static void launch_cfg_dma(const ConvKernelArgs &k, hipStream_t s) {
+    if (k.fmt_x != FMT_H16 || k.Cin % 32) fail("conv: the LDS-DMA kernel needs a pre-split (H16) input");
+#define YDS_CALL(A, R) launch_inst_dma<BM, BN, NS, A, R>(k, s)
+    YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+}
+
 template <int BM, int BN, int ACT, int RES, int AIN> static void launch_inst16(ConvKernelArgs k, hipStream_t s) {
     constexpr size_t smem = 2ull * (BM + BN) * ROWB;
     static bool attr_set = false;
@@ -215,7 +398,8 @@ template <int BM, int BN> static void launch_cfg16(const ConvKernelArgs &k, hipS
 
 const char *conv_f16x3_variant_name(int v) {
     static const char *names[kF16Variants] = {"conv_igemm_f16x3<128,128>", "conv_igemm_f16x3<64,128>", "conv_igemm_f16x3<128,64>",
-                                              "conv_igemm_f16x3<64,64>"};
+                                              "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,5>", "conv_igemm_f16x3_dma<128,128,4>",
+                                              "conv_igemm_f16x3_dma<64,128,5>", "conv_igemm_f16x3_dma<64,64,6>"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
 }
 
@@ -224,7 +408,11 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s) {
         case 0: launch_cfg16<128, 128>(k, s); break;
         case 1: launch_cfg16<64, 128>(k, s); break;
         case 2: launch_cfg16<128, 64>(k, s); break;
-        default: launch_cfg16<64, 64>(k, s); break;
+        case 3: launch_cfg16<64, 64>(k, s); break;
+        case 4: launch_cfg_dma<128, 128, 5>(k, s); break;
+        case 5: launch_cfg_dma<128, 128, 4>(k, s); break;
+        case 6: launch_cfg_dma<64, 128, 5>(k, s); break;
+        default: launch_cfg_dma<64, 64, 6>(k, s); break;
     }
 }
 
