@@ -55,6 +55,140 @@ def test_mini_every_layer_vs_oracle_and_golden():
     _close(out2[1:2], ref.forward(x2[1:2]))
 
 
+WIDE_CFG = """
+[net]
+channels=3
+height=64
+width=64
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=2
+pad=1
+activation=mish
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=mish
+
+# conv 2 is read by the shortcut AND by the route below: the shortcut cannot be fused into it
+[shortcut]
+from=-2
+activation=linear
+
+[route]
+layers=-2,-1
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[route]
+layers=-1
+groups=2
+group_id=1
+
+[maxpool]
+size=2
+stride=1
+
+[maxpool]
+size=5
+stride=1
+
+[route]
+layers=-1,-2,-3
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[maxpool]
+size=2
+stride=2
+
+[upsample]
+stride=2
+
+# conv 5 feeds two different concatenations: the second one has to fall back to a copy
+[route]
+layers=-1,5
+
+[route]
+layers=5,-4
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=mish
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=255
+activation=linear
+
+[yolo]
+mask = 0,1,2
+anchors = 10,14,  23,27,  37,58,  81,82,  135,169,  344,319
+classes=80
+num=6
+"""
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_wide_net_pre_split_layout_paths_vs_oracle(mode):
+    """32-channel-multiple graph: exercises the pre-split (H16) tensor format through an unfused shortcut, grouped and
+    multi-source routes (slice writes and copy fallback), zero-padded and SPP max pools and the upsample."""
+    from yolo_deepsort_amd import _lib
+    lib = _lib.load()
+    default = lib.yds_get_conv_math()
+    try:
+        lib.yds_set_conv_math(mode)
+        net, ref = _nets(WIDE_CFG, (64, 64), 5, -1.0, batch_max=2)
+        x = np.random.RandomState(7).rand(2, 3, 64, 64).astype(F32)
+        out = net(x)
+        want = ref.forward(x, keep_layers=True)
+        for i, d in enumerate(ref.module_defs):
+            if d["type"] == "yolo":
+                continue
+            try:
+                got = net.layer_output(i, 2)
+            except Exception as e:
+                assert "fused" in str(e)
+                continue
+            _close(got, ref.layer_outputs[i], 1e-4, 1e-4, f"layer {i} {d['type']}")
+        _close(out, want)
+    finally:
+        lib.yds_set_conv_math(default)
+
+
 def test_both_math_modes_meet_the_tolerance():
     """f16x3 (default, split-fp16 MFMA) and the exact fp32 MFMA path against the reference's golden vector."""
     from yolo_deepsort_amd import _lib
