@@ -79,35 +79,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
             a_base[i] = 0;
         }
     }
-    int kk = cq * 4, kh = 0, kw = 0, kc = kk;
-    while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
-    const char *w_row[B_ROWS];
+    // K position of the tile being loaded.  With a pre-split input Cin % 32 == 0, so a 32-wide K step is one
+    // 32-channel group of ONE filter tap for every lane: tap and group offset are wave-uniform (scalar registers),
+    // the per-row pixel offset + bounds test are recomputed only when the tap changes, and the loads take a scalar
+    // base + 32-bit per-lane offset (no per-step address arithmetic on the vector ALU).  fp32 inputs (the image,
+    // narrow nets) keep the general per-lane decomposition: there a K step can straddle taps.
+    int kk = cq * 4, kh = 0, kw = 0, kc = AIN == FMT_H16 ? 0 : kk;
+    if (AIN != FMT_H16)
+        while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
+    unsigned w_off[B_ROWS];
 #pragma unroll
-    for (int i = 0; i < B_ROWS; ++i)
-        w_row[i] = reinterpret_cast<const char *>(p.w) + (size_t)min(n0 + r0 + 32 * i, p.Cout - 1) * p.Kpad * 4 + cq * 16;
+    for (int i = 0; i < B_ROWS; ++i) w_off[i] = (unsigned)min(n0 + r0 + 32 * i, p.Cout - 1) * (unsigned)p.Kpad * 4u + cq * 16;
+    const char *w_bytes = reinterpret_cast<const char *>(p.w), *x_bytes = reinterpret_cast<const char *>(p.x);
 
     f32x4 a_reg[A_ROWS], b_reg[B_ROWS];
-    unsigned a_ok = 0;
+    unsigned a_ok = 0, a_off[A_ROWS], tap_ok = 0;
     int kt_load = 0;
-    auto load_tiles = [&]() {
-        const int tap_off = (kh * p.W + kw) * p.ldx + kc;
-        const bool k_ok = kk < p.K;
-        a_ok = 0;
+    auto set_tap = [&]() {                                     // H16 path: per-row byte offset + bounds of tap (kh, kw)
+        tap_ok = 0;
 #pragma unroll
         for (int i = 0; i < A_ROWS; ++i) {
             int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
-            bool ok = k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            a_ok |= (ok ? 1u : 0u) << i;
-            a_reg[i] = *reinterpret_cast<const f32x4 *>(p.x + (ok ? a_base[i] + tap_off : 0));
+            bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            tap_ok |= (ok ? 1u : 0u) << i;
+            a_off[i] = ok ? (unsigned)(a_base[i] + (kh * p.W + kw) * p.ldx + cq * 4) * 4u : cq * 16u;
         }
+    };
+    if (AIN == FMT_H16) set_tap();
+    auto load_tiles = [&]() {
+        if (AIN == FMT_H16) {
+            a_ok = tap_ok;
+            const char *xg = x_bytes + (size_t)kc * 4;           // uniform: channel-group base of this K step
 #pragma unroll
-        for (int i = 0; i < B_ROWS; ++i) b_reg[i] = *reinterpret_cast<const f32x4 *>(w_row[i] + (size_t)kt_load * 128);
+            for (int i = 0; i < A_ROWS; ++i) a_reg[i] = *reinterpret_cast<const f32x4 *>(xg + a_off[i]);
+        } else {
+            const int tap_off = (kh * p.W + kw) * p.ldx + kc;
+            const bool k_ok = kk < p.K;
+            a_ok = 0;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
+                bool ok = k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                a_ok |= (ok ? 1u : 0u) << i;
+                a_reg[i] = *reinterpret_cast<const f32x4 *>(p.x + (ok ? a_base[i] + tap_off : 0));
+            }
+        }
+        const char *wg = w_bytes + (size_t)kt_load * 128;        // uniform
+#pragma unroll
+        for (int i = 0; i < B_ROWS; ++i) b_reg[i] = *reinterpret_cast<const f32x4 *>(wg + w_off[i]);
     };
     auto advance_k = [&]() {
         ++kt_load;
         kk += 32;
         kc += 32;
-        while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
+        if (AIN == FMT_H16) {
+            if (kc >= p.Cin) { kc = 0; if (++kw == p.ksize) { kw = 0; ++kh; } set_tap(); }
+        } else {
+            while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
+        }
     };
     auto store_tiles = [&](int buf) {
         char *a = As + buf * BM * ROWB, *b = Bs + buf * BN * ROWB;
