@@ -209,6 +209,7 @@ const char *conv_variant_name(int v) {
     static const char *names[kF32Variants] = {"conv_igemm_f32<128,128,2,2,32>", "conv_igemm_f32<128,64,2,2,32>", "conv_igemm_f32<64,64,2,2,32>",
                                                "conv_igemm_f32<128,32,4,1,32>", "conv_igemm_f32<128,128,2,2,16>", "conv_igemm_f32<128,64,2,2,16>",
                                                "conv_igemm_f32<64,128,2,2,16>"};
+    if (v == kDirectVariant) return "conv3x3_rgb_direct";
     if (v >= kF32Variants) return conv_f16x3_variant_name(v - kF32Variants);
     return v >= 0 ? names[v] : "?";
 }
@@ -260,6 +261,11 @@ int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
         variant = conv_default_variant(a);
         if (conv_math() == MATH_F16X3) variant = kF32Variants + (variant == 0 ? 0 : variant == 1 ? 2 : 3);
     }
+    if (variant == kDirectVariant) {
+        if (!conv_direct_applicable(k)) fail("conv: the direct RGB kernel does not apply to this layer");
+        launch_conv_direct(k, s);
+        return variant;
+    }
     if (variant < kF32Variants && (k.fmt_x != FMT_F32 || k.fmt_y != FMT_F32 || k.fmt_r != FMT_F32))
         fail("conv: the fp32 MFMA kernel takes fp32 tensors only");
     if (variant >= kF32Variants) {
@@ -294,21 +300,33 @@ int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
 // Measured tile choice: times every instantiation on the real buffers (HIP events, median of 3) and returns the
 // fastest.  Wave quantisation on 256 CUs makes the best tile shape a function of (M, N, K, batch) that a closed
 // form predicts poorly, and the measurement costs a few milliseconds per layer at plan time.
+static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_us);
+
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
     if (const char *f = getenv("YDS_CONV_FORCE")) {      // tuning aid: pin a variant id where it is applicable
         int v = atoi(f);
-        bool dma = v >= kF32Variants + 4;
+        bool dma = v >= kF32Variants + 4 && v != kDirectVariant;
+        if (v == kDirectVariant && !conv_direct_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (!(dma && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
+    return conv_autotune_measured(a, s, best_us);
+}
+
+static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_us) {
     hipEvent_t e0, e1;
     YDS_HIP(hipEventCreate(&e0));
     YDS_HIP(hipEventCreate(&e1));
     int best = -1;
     float best_t = 0.f;
-    const int v_lo = conv_math() == MATH_F16X3 ? kF32Variants : 0, v_hi = conv_math() == MATH_F16X3 ? kConvVariants : kF32Variants;
-    for (int v = v_lo; v < v_hi; ++v) {
+    const bool direct_ok = conv_direct_applicable(make_conv_args(a));
+    const int v_lo = conv_math() == MATH_F16X3 ? kF32Variants : 0, v_hi = conv_math() == MATH_F16X3 ? kDirectVariant : kF32Variants;
+    for (int v = v_lo; v <= v_hi; ++v) {
+        if (v == v_hi) {                                 // last candidate: the direct first-layer kernel
+            if (!direct_ok) break;
+            v = kDirectVariant;
+        }
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
-        if (v >= kF32Variants + 4 && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // LDS-DMA tiles need a pre-split input
+        if (v != kDirectVariant && v >= kF32Variants + 4 && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // LDS-DMA tiles need a pre-split input
         launch_conv(a, s, v);
         float t[3];
         for (int r = 0; r < 3; ++r) {

@@ -147,6 +147,10 @@ ConvKernelArgs make_conv_args(const ConvArgs &a);
         default: fail("conv: unsupported activation/residual combination (%d, %d)", (k).act, (k).res_mode); \
     }
 
+// direct first-layer kernel (conv_first.hip)
+bool conv_direct_applicable(const ConvKernelArgs &k);
+void launch_conv_direct(const ConvKernelArgs &k, hipStream_t s);
+
 // split-fp16 path (conv_f16x3.hip)
 constexpr int kF16Variants = 8;            // 0-3 register-staged tiles, 4-7 LDS-DMA ring (pre-split inputs only)
 const char *conv_f16x3_variant_name(int v);
