@@ -103,19 +103,19 @@ private:
 // Device multi-label NMS over decoded predictions [n_boxes, attrs] (nms.hip).
 class NmsWorkspace {
 public:
-    explicit NmsWorkspace(int max_candidates = 16384);
+    explicit NmsWorkspace(int max_candidates = 16384, int frames = 1);
     ~NmsWorkspace();
     NmsWorkspace(const NmsWorkspace &) = delete;
     // asynchronous form: launch() enqueues the kernels and the copies into pinned host memory, collect() reads
     // them after the caller synchronised the stream
-    void launch(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy, int cap,
-                hipStream_t s);
-    int collect(float *out6_host, int cap);
+    void launch(const float *pred_dev, size_t pred_stride, int n_frames, int n_boxes, int attrs, float conf_thres, float iou_thres,
+                float sx, float sy, int cap, hipStream_t s);
+    int collect(int frame, float *out6_host, int cap);
     // returns number of rows written to out6_host (<= cap); rows sorted by score, boxes in model pixels
     // scaled by (sx, sy) when scale is requested (resize_boxes).
     int run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
             float *out6_host, int cap, hipStream_t s);
-    int max_cand;
+    int max_cand, frames;
     DevBuf<float> cand;          // [max_cand, 6]   x1,y1,x2,y2,score,cls in candidate order
     DevBuf<float> sorted;        // [max_cand, 6]   score order
     DevBuf<int> counts;          // [0] n candidates, [1] n kept

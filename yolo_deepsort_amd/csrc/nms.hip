@@ -23,7 +23,9 @@ namespace yds {
 
 constexpr int MAX_DET = 300;
 
-__global__ void nms_count_kernel(const float *pred, int n_boxes, int attrs, float thr, int *box_count) {
+__global__ void nms_count_kernel(const float *pred_all, size_t pred_stride, int n_boxes, int attrs, float thr, int *box_count_all) {
+    const float *pred = pred_all + blockIdx.y * pred_stride;
+    int *box_count = box_count_all + (size_t)blockIdx.y * n_boxes;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_boxes) return;
     const float *p = pred + (size_t)i * attrs;
@@ -36,7 +38,9 @@ __global__ void nms_count_kernel(const float *pred, int n_boxes, int attrs, floa
 }
 
 // single-workgroup exclusive scan, in place; total -> counts[0]
-__global__ void nms_scan_kernel(int *box_count, int n_boxes, int *counts) {
+__global__ void nms_scan_kernel(int *box_count_all, int n_boxes, int *counts_all) {
+    int *box_count = box_count_all + (size_t)blockIdx.y * n_boxes;
+    int *counts = counts_all + blockIdx.y * 4;
     __shared__ int wave_sum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,7 +67,11 @@ __global__ void nms_scan_kernel(int *box_count, int n_boxes, int *counts) {
     if (tid == 0) { counts[0] = carry; counts[1] = 0; }
 }
 
-__global__ void nms_emit_kernel(const float *pred, int n_boxes, int attrs, float thr, const int *box_off, int max_cand, float *cand) {
+__global__ void nms_emit_kernel(const float *pred_all, size_t pred_stride, int n_boxes, int attrs, float thr, const int *box_off_all, int max_cand,
+                                float *cand_all) {
+    const float *pred = pred_all + blockIdx.y * pred_stride;
+    const int *box_off = box_off_all + (size_t)blockIdx.y * n_boxes;
+    float *cand = cand_all + (size_t)blockIdx.y * max_cand * 6;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_boxes) return;
     const float *p = pred + (size_t)i * attrs;
@@ -84,7 +92,10 @@ __global__ void nms_emit_kernel(const float *pred, int n_boxes, int attrs, float
     }
 }
 
-__global__ void nms_rank_kernel(const float *cand, const int *counts, int max_cand, float *sorted) {
+__global__ void nms_rank_kernel(const float *cand_all, const int *counts_all, int max_cand, float *sorted_all) {
+    const float *cand = cand_all + (size_t)blockIdx.y * max_cand * 6;
+    float *sorted = sorted_all + (size_t)blockIdx.y * max_cand * 6;
+    const int *counts = counts_all + blockIdx.y * 4;
     __shared__ float tile[256];
     const int n = min(counts[0], max_cand);
     for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
@@ -115,7 +126,10 @@ __device__ __forceinline__ void offset_box(const float *r, float b[4]) {
     b[0] = __fadd_rn(r[0], c); b[1] = __fadd_rn(r[1], c); b[2] = __fadd_rn(r[2], c); b[3] = __fadd_rn(r[3], c);
 }
 
-__global__ void nms_mask_kernel(const float *sorted, const int *counts, int max_cand, double thr, unsigned long long *mask, int words_ld) {
+__global__ void nms_mask_kernel(const float *sorted_all, const int *counts_all, int max_cand, double thr, unsigned long long *mask_all, int words_ld) {
+    const float *sorted = sorted_all + (size_t)blockIdx.y * max_cand * 6;
+    const int *counts = counts_all + blockIdx.y * 4;
+    unsigned long long *mask = mask_all + (size_t)blockIdx.y * max_cand * words_ld;
     const int n = min(counts[0], max_cand);
     const int words = (n + 63) / 64;
     const long total = (long)n * words;
@@ -145,8 +159,12 @@ __global__ void nms_mask_kernel(const float *sorted, const int *counts, int max_
     }
 }
 
-__global__ void nms_sweep_kernel(const float *sorted, const unsigned long long *mask, int words_ld, int *counts, int max_cand,
-                                 float sx, float sy, float *kept, int cap) {
+__global__ void nms_sweep_kernel(const float *sorted_all, const unsigned long long *mask_all, int words_ld, int *counts_all, int max_cand,
+                                 float sx, float sy, float *kept_all, int cap) {
+    const float *sorted = sorted_all + (size_t)blockIdx.y * max_cand * 6;
+    const unsigned long long *mask = mask_all + (size_t)blockIdx.y * max_cand * words_ld;
+    int *counts = counts_all + blockIdx.y * 4;
+    float *kept = kept_all + (size_t)blockIdx.y * MAX_DET * 6;
     extern __shared__ unsigned long long removed[];
     __shared__ int n_keep;
     const int n = min(counts[0], max_cand);
@@ -176,14 +194,14 @@ __global__ void nms_sweep_kernel(const float *sorted, const unsigned long long *
     if (threadIdx.x == 0) counts[1] = n_keep;
 }
 
-NmsWorkspace::NmsWorkspace(int max_candidates) : max_cand(max_candidates) {
-    cand.alloc((size_t)max_cand * 6);
-    sorted.alloc((size_t)max_cand * 6);
-    counts.alloc(4);
-    mask.alloc((size_t)max_cand * (max_cand / 64));
-    kept.alloc((size_t)MAX_DET * 6);
-    YDS_HIP(hipHostMalloc((void **)&h_counts, 4 * sizeof(int)));
-    YDS_HIP(hipHostMalloc((void **)&h_kept, (size_t)MAX_DET * 6 * sizeof(float)));
+NmsWorkspace::NmsWorkspace(int max_candidates, int frames) : max_cand(max_candidates), frames(frames) {
+    cand.alloc((size_t)frames * max_cand * 6);
+    sorted.alloc((size_t)frames * max_cand * 6);
+    counts.alloc((size_t)frames * 4);
+    mask.alloc((size_t)frames * max_cand * (max_cand / 64));
+    kept.alloc((size_t)frames * MAX_DET * 6);
+    YDS_HIP(hipHostMalloc((void **)&h_counts, (size_t)frames * 4 * sizeof(int)));
+    YDS_HIP(hipHostMalloc((void **)&h_kept, (size_t)frames * MAX_DET * 6 * sizeof(float)));
 }
 
 NmsWorkspace::~NmsWorkspace() {
@@ -191,37 +209,41 @@ NmsWorkspace::~NmsWorkspace() {
     if (h_kept) (void)hipHostFree(h_kept);
 }
 
-void NmsWorkspace::launch(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy, int cap,
-                          hipStream_t s) {
+// All `n_frames` images go through each stage in ONE launch (blockIdx.y = image).
+void NmsWorkspace::launch(const float *pred_dev, size_t pred_stride, int n_frames, int n_boxes, int attrs, float conf_thres, float iou_thres,
+                          float sx, float sy, int cap, hipStream_t s) {
     if (attrs < 6) fail("nms: predictions need at least one class");
-    box_count.ensure(n_boxes);
+    if (n_frames < 1 || n_frames > frames) fail("nms: %d frames outside the workspace capacity %d", n_frames, frames);
+    box_count.ensure((size_t)frames * n_boxes);
     const int nb = (n_boxes + 255) / 256;
-    hipLaunchKernelGGL(nms_count_kernel, dim3(nb), dim3(256), 0, s, pred_dev, n_boxes, attrs, conf_thres, box_count.p);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, s, box_count.p, n_boxes, counts.p);
-    hipLaunchKernelGGL(nms_emit_kernel, dim3(nb), dim3(256), 0, s, pred_dev, n_boxes, attrs, conf_thres, box_count.p, max_cand, cand.p);
-    hipLaunchKernelGGL(nms_rank_kernel, dim3(64), dim3(256), 0, s, cand.p, counts.p, max_cand, sorted.p);
+    hipLaunchKernelGGL(nms_count_kernel, dim3(nb, n_frames), dim3(256), 0, s, pred_dev, pred_stride, n_boxes, attrs, conf_thres, box_count.p);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1, n_frames), dim3(1024), 0, s, box_count.p, n_boxes, counts.p);
+    hipLaunchKernelGGL(nms_emit_kernel, dim3(nb, n_frames), dim3(256), 0, s, pred_dev, pred_stride, n_boxes, attrs, conf_thres, box_count.p,
+                       max_cand, cand.p);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3(16, n_frames), dim3(256), 0, s, cand.p, counts.p, max_cand, sorted.p);
     const int words_ld = max_cand / 64;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(512), dim3(256), 0, s, sorted.p, counts.p, max_cand, (double)iou_thres, mask.p, words_ld);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), words_ld * sizeof(unsigned long long), s, sorted.p, mask.p, words_ld, counts.p,
-                       max_cand, sx, sy, kept.p, cap);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(64, n_frames), dim3(256), 0, s, sorted.p, counts.p, max_cand, (double)iou_thres, mask.p, words_ld);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1, n_frames), dim3(256), words_ld * sizeof(unsigned long long), s, sorted.p, mask.p, words_ld,
+                       counts.p, max_cand, sx, sy, kept.p, cap);
     YDS_HIP(hipGetLastError());
     // results land in pinned host memory; the caller synchronises the stream (or an event) before collect()
-    YDS_HIP(hipMemcpyAsync(h_counts, counts.p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-    YDS_HIP(hipMemcpyAsync(h_kept, kept.p, (size_t)MAX_DET * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipMemcpyAsync(h_counts, counts.p, (size_t)n_frames * 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipMemcpyAsync(h_kept, kept.p, (size_t)n_frames * MAX_DET * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
 }
 
-int NmsWorkspace::collect(float *out6_host, int cap) {
-    if (h_counts[0] > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (raise conf_thres)", h_counts[0], max_cand);
-    int n = h_counts[1] < cap ? h_counts[1] : cap;
-    if (n > 0) memcpy(out6_host, h_kept, (size_t)n * 6 * sizeof(float));
+int NmsWorkspace::collect(int frame, float *out6_host, int cap) {
+    const int *c = h_counts + frame * 4;
+    if (c[0] > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (raise conf_thres)", c[0], max_cand);
+    int n = c[1] < cap ? c[1] : cap;
+    if (n > 0) memcpy(out6_host, h_kept + (size_t)frame * MAX_DET * 6, (size_t)n * 6 * sizeof(float));
     return n;
 }
 
 int NmsWorkspace::run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
                       float *out6_host, int cap, hipStream_t s) {
-    launch(pred_dev, n_boxes, attrs, conf_thres, iou_thres, sx, sy, cap, s);
+    launch(pred_dev, 0, 1, n_boxes, attrs, conf_thres, iou_thres, sx, sy, cap, s);
     YDS_HIP(hipStreamSynchronize(s));
-    return collect(out6_host, cap);
+    return collect(0, out6_host, cap);
 }
 
 }  // namespace yds

@@ -24,7 +24,7 @@ public:
     Pipeline(Darknet *net, ReidNet *reid, TrackerIface *trk, float conf, float nms_iou, const int32_t *mask, int n_mask)
         : net(net), reid(reid), trk(trk), conf(conf), nms_thres(nms_iou), class_mask(mask, mask + n_mask) {
         for (hipEvent_t *e : {&e0, &e1, &e2, &e_nms}) YDS_HIP(hipEventCreate(e));
-        for (int b = 0; b < net->batch_max; ++b) nms.emplace_back(new NmsWorkspace(4096));
+        nms.reset(new NmsWorkspace(4096, net->batch_max));
     }
     ~Pipeline() {
         for (hipEvent_t e : {e0, e1, e2, e_nms}) (void)hipEventDestroy(e);
@@ -50,9 +50,8 @@ public:
         in_flight = nullptr;
         // NMS of every frame behind the detector, results into pinned host buffers
         const float sx = (float)((double)w / net->img_w), sy = (float)((double)h / net->img_h);
-        for (int b = 0; b < batch; ++b)
-            nms[b]->launch(net->out.p + (size_t)b * net->total_boxes * net->attrs, net->total_boxes, net->attrs, conf, nms_thres, sx, sy,
-                           300, net->stream);
+        nms->launch(net->out.p, (size_t)net->total_boxes * net->attrs, batch, net->total_boxes, net->attrs, conf, nms_thres, sx, sy, 300,
+                    net->stream);
         YDS_HIP(hipEventRecord(e_nms, net->stream));
         YDS_HIP(hipEventSynchronize(e_nms));
         float ms01 = 0, ms12 = 0;
@@ -69,7 +68,7 @@ public:
         tlwh.clear(); payload.clear(); frame_of.clear();
         std::vector<int> first(batch + 1, 0), n_det(batch, 0);
         for (int b = 0; b < batch; ++b) {
-            n_det[b] = nms[b]->collect(det.data(), 300);
+            n_det[b] = nms->collect(b, det.data(), 300);
             for (int i = 0; i < n_det[b]; ++i) {
                 const float *r = &det[i * 6];
                 bool keep = class_mask.empty();
@@ -105,7 +104,7 @@ public:
     TrackerIface *trk;
     float conf, nms_thres;
     std::vector<int32_t> class_mask;
-    std::vector<std::unique_ptr<NmsWorkspace>> nms;
+    std::unique_ptr<NmsWorkspace> nms;
     std::vector<float> tlwh, payload;
     std::vector<int> frame_of;
     int next_inject_set = -1;      // bench-only: injection set of the prefetched detector pass
