@@ -16,6 +16,8 @@
 //   Epilogue: bias + activation (+ residual, before or after the activation) and 128-byte row stores.
 #include "conv_common.h"
 
+#include <map>
+#include <string>
 #include <string.h>
 
 namespace yds {
@@ -302,6 +304,31 @@ int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
 // form predicts poorly, and the measurement costs a few milliseconds per layer at plan time.
 static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_us);
 
+// Optional on-disk cache of measured choices (env YDS_TUNE_CACHE=<file>): lets a profiled run reuse the choices of a
+// previous run instead of timing every variant again under the profiler.
+static std::map<std::string, int> &tune_cache() {
+    static std::map<std::string, int> cache;
+    static bool loaded = false;
+    if (!loaded) {
+        loaded = true;
+        if (const char *path = getenv("YDS_TUNE_CACHE")) {
+            if (FILE *f = fopen(path, "r")) {
+                char key[256];
+                int v;
+                while (fscanf(f, "%255s %d", key, &v) == 2) cache[key] = v;
+                fclose(f);
+            }
+        }
+    }
+    return cache;
+}
+static std::string tune_key(const ConvArgs &a) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d", conv_math(), a.x.n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
+             a.y.h, a.y.w, a.ksize, a.stride, a.act, a.res.p ? a.res_mode : 0, a.x.fmt, a.y.fmt);
+    return buf;
+}
+
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
     if (const char *f = getenv("YDS_CONV_FORCE")) {      // tuning aid: pin a variant id where it is applicable
         int v = atoi(f);
@@ -309,7 +336,16 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
         if (v == kDirectVariant && !conv_direct_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (!(dma && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
-    return conv_autotune_measured(a, s, best_us);
+    const std::string key = tune_key(a);
+    auto &cache = tune_cache();
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int v = conv_autotune_measured(a, s, best_us);
+    cache[key] = v;
+    if (const char *path = getenv("YDS_TUNE_CACHE")) {
+        if (FILE *f = fopen(path, "a")) { fprintf(f, "%s %d\n", key.c_str(), v); fclose(f); }
+    }
+    return v;
 }
 
 static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_us) {
