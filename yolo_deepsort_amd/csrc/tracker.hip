@@ -178,53 +178,70 @@ __global__ void gating_kernel(const float *mean, const float *cov, const int *sl
 }
 
 // ------------------------------------------------------------------------------------- appearance cost
-// cost[t][d] = min over the gallery rows of track t of 1 - <g/|g|, f/|f|>, then Mahalanobis gate and
-// the min_cost_matching clamp.  One workgroup per (track, 16-detection slab); detections are normalised
-// into LDS once, each thread owns (gallery row, detection) pairs.
-__global__ void appearance_cost_kernel(const float *gallery, const int *slots, const int *n_rows, int budget, const float *feats,
-                                       const int *det_idx, int D, const float *mean, const float *cov, const float *tlwh,
-                                       float max_dist, float flood, int do_gate, float *cost) {
-    __shared__ float fs[16][EMB + 1];
-    __shared__ float best[16];
+// cost[t][d] = min over the gallery rows of track t of 1 - <g/|g|, f/|f|>, then Mahalanobis gate and the
+// min_cost_matching clamp.  Gallery rows are normalised once when they are appended and detections once per frame
+// (normalize_rows_kernel) - the same division the reference repeats on every call.  One workgroup per (track,
+// 16-detection slab): the slab and 16 gallery rows at a time sit in LDS (rows padded by one float: conflict free),
+// thread (r, d) owns one dot product per chunk and keeps a running minimum.
+__global__ void normalize_rows_kernel(const float *src, const int *src_idx, float *dst, int n) {
+    // one wave per row: dst[row] = src[idx[row]] / ||src[idx[row]]||
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const float *f = src + (size_t)(src_idx ? src_idx[row] : row) * EMB;
+    float v[EMB / 64], ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < EMB / 64; ++k) { v[k] = f[lane + 64 * k]; ss += v[k] * v[k]; }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = sqrtf(ss);
+#pragma unroll
+    for (int k = 0; k < EMB / 64; ++k) dst[(size_t)row * EMB + lane + 64 * k] = v[k] / nrm;
+}
+
+__global__ __launch_bounds__(256) void appearance_cost_kernel(const float *gallery_n, const int *slots, const int *n_rows, int budget,
+                                                             const float *feats_n, int D, const float *mean, const float *cov,
+                                                             const float *tlwh, float max_dist, float flood, int do_gate, float *cost) {
+    __shared__ float fs[16][EMB + 1], gs[16][EMB + 1];
+    __shared__ float best[16][17];
     const int t = blockIdx.x, d0 = blockIdx.y * 16;
     const int nd = min(16, D - d0);
-    const int slot = slots[t];
-    // load + normalise this slab of detections
-    for (int d = threadIdx.x >> 4; d < nd; d += blockDim.x >> 4) {
-        const float *f = feats + (size_t)det_idx[d0 + d] * EMB;
-        const int l = threadIdx.x & 15;
-        float ss = 0.f;
-        for (int k = l; k < EMB; k += 16) ss += f[k] * f[k];
-        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
-        float nrm = sqrtf(ss);
-        for (int k = l; k < EMB; k += 16) fs[d][k] = f[k] / nrm;
+    const int slot = slots[t], rows = n_rows[t];
+    for (int i = threadIdx.x; i < 16 * (EMB / 4); i += blockDim.x) {        // detection slab, float4 coalesced
+        const int d = i / (EMB / 4), k4 = i % (EMB / 4);
+        float4 v = d < nd ? *reinterpret_cast<const float4 *>(feats_n + (size_t)(d0 + d) * EMB + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        fs[d][k4 * 4] = v.x; fs[d][k4 * 4 + 1] = v.y; fs[d][k4 * 4 + 2] = v.z; fs[d][k4 * 4 + 3] = v.w;
     }
-    if (threadIdx.x < 16) best[threadIdx.x] = INFINITY;
-    __syncthreads();
-    const int rows = n_rows[t];
-    for (int pair = threadIdx.x; pair < rows * nd; pair += blockDim.x) {
-        int g = pair / nd, d = pair - g * nd;
-        const float *gr = gallery + ((size_t)slot * budget + g) * EMB;
-        float gg = 0.f, dot = 0.f;
-        for (int k = 0; k < EMB; ++k) gg += gr[k] * gr[k];
-        float gn = sqrtf(gg);
-        for (int k = 0; k < EMB; ++k) dot += (gr[k] / gn) * fs[d][k];
-        float c = 1.f - dot;
-        // fp32 min via integer atomics on the ordered bit pattern is overkill here: serialise per slab
-        atomicMin(reinterpret_cast<int *>(&best[d]), c >= 0.f ? __float_as_int(c) : (int)0x80000000 - __float_as_int(c));
+    const int r = threadIdx.x >> 4, d = threadIdx.x & 15;
+    float run_min = INFINITY;
+    for (int g0 = 0; g0 < rows; g0 += 16) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * (EMB / 4); i += blockDim.x) {
+            const int g = i / (EMB / 4), k4 = i % (EMB / 4);
+            float4 v = g0 + g < rows ? *reinterpret_cast<const float4 *>(gallery_n + ((size_t)slot * budget + g0 + g) * EMB + k4 * 4)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            gs[g][k4 * 4] = v.x; gs[g][k4 * 4 + 1] = v.y; gs[g][k4 * 4 + 2] = v.z; gs[g][k4 * 4 + 3] = v.w;
+        }
+        __syncthreads();
+        if (g0 + r < rows) {
+            float dot = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < EMB; ++k) dot += gs[r][k] * fs[d][k];
+            run_min = fminf(run_min, 1.f - dot);
+        }
     }
+    best[r][d] = run_min;
     __syncthreads();
     if ((int)threadIdx.x < nd) {
-        int enc = reinterpret_cast<int *>(best)[threadIdx.x];
-        float c = enc >= 0 ? __int_as_float(enc) : __int_as_float((int)0x80000000 - enc);
-        const int d = d0 + threadIdx.x;
+        float c = INFINITY;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) c = fminf(c, best[q][threadIdx.x]);
+        const int dd = d0 + threadIdx.x;
         if (do_gate) {
             float z[4];
-            to_xyah(tlwh + (size_t)det_idx[d] * 4, z);
+            to_xyah(tlwh + (size_t)dd * 4, z);
             if (gate2(mean + (size_t)slot * 8, cov + (size_t)slot * 64, z) > CHI2_2DOF) c = INFTY_COST;
         }
         if (max_dist > 0.f && c > max_dist) c = flood;            // linear_assignment.py:52
-        cost[(size_t)t * D + d] = c;
+        cost[(size_t)t * D + dd] = c;
     }
 }
 
@@ -268,14 +285,24 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void lsap_kernel(const float *cost, int nr0, int nc0, int *row_out, int *col_out) {
+__global__ __launch_bounds__(64) void lsap_kernel(const float *cost, int nr0, int nc0, int *row_out, int *col_out, int cost_in_lds) {
     const int lane = threadIdx.x;
     const bool transpose = nc0 < nr0;
     const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
-    // all solver state lives in LDS (48 KiB for LSAP_MAX = 1024)
-    __shared__ double u[LSAP_MAX], v[LSAP_MAX], spc[LSAP_MAX];
-    __shared__ int path[LSAP_MAX], col4row[LSAP_MAX], row4col[LSAP_MAX], remaining[LSAP_MAX], SR[LSAP_MAX], SC[LSAP_MAX];
-    auto C = [&](int i, int j) -> double { return (double)(transpose ? cost[(size_t)j * nc0 + i] : cost[(size_t)i * nc0 + j]); };
+    // all solver state lives in LDS; when it fits, so does the cost matrix (the augmenting-path scan is a chain of
+    // dependent lookups: one L2 round trip per Dijkstra step was most of the kernel's time)
+    extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
+    const int n = max(nr, nc);
+    double *u = reinterpret_cast<double *>(lsap_smem), *v = u + n, *spc = v + n;
+    int *path = reinterpret_cast<int *>(spc + n), *col4row = path + n, *row4col = col4row + n, *remaining = row4col + n, *SR = remaining + n,
+        *SC = SR + n;
+    float *cost_lds = reinterpret_cast<float *>(SC + n);
+    if (cost_in_lds) {
+        for (int i = lane; i < nr0 * nc0; i += 64) cost_lds[i] = cost[i];
+        __syncthreads();
+    }
+    const float *cm = cost_in_lds ? cost_lds : cost;
+    auto C = [&](int i, int j) -> double { return (double)(transpose ? cm[(size_t)j * nc0 + i] : cm[(size_t)i * nc0 + j]); };
     for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
     for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
     __syncthreads();
@@ -352,13 +379,28 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *cost, int nr0, in
     }
 }
 
+static void launch_lsap(const float *cost_dev, int nr, int nc, int *rows_dev, int *cols_dev, hipStream_t s) {
+    const int n = nr > nc ? nr : nc;
+    size_t state = (size_t)n * (3 * sizeof(double) + 6 * sizeof(int)), with_cost = state + (size_t)nr * nc * sizeof(float);
+    const bool in_lds = with_cost <= 150 * 1024;
+    const size_t smem = in_lds ? with_cost : state;
+    static bool attr_set = false;
+    if (!attr_set) {
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(64), smem, s, cost_dev, nr, nc, rows_dev, cols_dev, in_lds ? 1 : 0);
+    YDS_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ misc
-__global__ void feature_append_kernel(float *gallery, int budget, const int *slots, const int *pos, const float *feats, const int *det_idx,
+// appends the (already normalised) detection feature det_idx[t] to the gallery ring of slot slots[t]
+__global__ void feature_append_kernel(float *gallery_n, int budget, const int *slots, const int *pos, const float *feats_n, const int *det_idx,
                                       int n) {
     int t = blockIdx.x;
     if (t >= n) return;
-    float *dst = gallery + ((size_t)slots[t] * budget + pos[t]) * EMB;
-    const float *src = feats + (size_t)det_idx[t] * EMB;
+    float *dst = gallery_n + ((size_t)slots[t] * budget + pos[t]) * EMB;
+    const float *src = feats_n + (size_t)det_idx[t] * EMB;
     for (int k = threadIdx.x; k < EMB; k += blockDim.x) dst[k] = src[k];
 }
 
@@ -391,10 +433,15 @@ public:
         if (budget < 1) fail("tracker: nn_budget must be >= 1 (unbounded galleries are not supported)");
         YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         grow(256);
+        YDS_HIP(hipHostMalloc((void **)&ibuf_host, IBUF_INTS * sizeof(int), hipHostMallocMapped));
+        YDS_HIP(hipHostGetDevicePointer((void **)&ibuf_dev, ibuf_host, 0));
         lsap_rows.alloc(LSAP_MAX);
         lsap_cols.alloc(LSAP_MAX);
     }
-    ~Tracker() override { if (stream) (void)hipStreamDestroy(stream); }
+    ~Tracker() override {
+        if (ibuf_host) (void)hipHostFree(ibuf_host);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
     int num_tracks() const override { return (int)tracks.size(); }
 
     void grow(int cap) {
@@ -411,14 +458,17 @@ public:
     }
 
     // uploads an int vector into a scratch region and returns the device pointer
+    // Small index lists go through a pinned, device-mapped host ring: the kernels read them in place (a few hundred
+    // bytes over the host link) instead of paying one hipMemcpyAsync per list.  The ring is rewound once per step,
+    // after the step's final stream synchronisation.
     const int *up(const std::vector<int> &v) {
         if (v.empty()) return nullptr;
-        if (ibuf_used + v.size() > ibuf.n) fail("tracker: index scratch exhausted");
-        int *p = ibuf.p + ibuf_used;
-        keep_alive.push_back(v);      // the async copy reads a buffer that outlives this call
-        YDS_HIP(hipMemcpyAsync(p, keep_alive.back().data(), v.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        if (ibuf_used + v.size() > IBUF_INTS) fail("tracker: index scratch exhausted");
+        int *h = ibuf_host + ibuf_used;
+        memcpy(h, v.data(), v.size() * sizeof(int));
+        const int *d = ibuf_dev + ibuf_used;
         ibuf_used += (v.size() + 3) / 4 * 4;
-        return p;
+        return d;
     }
 
     struct Assignment { std::vector<int> rows, cols; std::vector<float> cost; };
@@ -426,8 +476,7 @@ public:
     void solve(const float *cost_dev, int nr, int nc, Assignment &a) {
         if (nr > LSAP_MAX || nc > LSAP_MAX) fail("tracker: assignment problem %dx%d exceeds %d", nr, nc, LSAP_MAX);
         int n = std::min(nr, nc);
-        hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(64), 0, stream, cost_dev, nr, nc, lsap_rows.p, lsap_cols.p);
-        YDS_HIP(hipGetLastError());
+        launch_lsap(cost_dev, nr, nc, lsap_rows.p, lsap_cols.p, stream);
         a.rows.resize(n); a.cols.resize(n); a.cost.resize((size_t)nr * nc);
         YDS_HIP(hipMemcpyAsync(a.rows.data(), lsap_rows.p, n * sizeof(int), hipMemcpyDeviceToHost, stream));
         YDS_HIP(hipMemcpyAsync(a.cols.data(), lsap_cols.p, n * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -450,9 +499,7 @@ public:
     }
 
     int step(const float *tlwh_host, const float *feats, bool feats_on_device, const float *payload, int D, int32_t *out6, int cap) override {
-        ibuf.ensure(1 << 16);
         ibuf_used = 0;
-        keep_alive.clear();
         const int T = (int)tracks.size();
         tlwh_dev.ensure((size_t)std::max(D, 1) * 4);
         if (D) YDS_HIP(hipMemcpyAsync(tlwh_dev.p, tlwh_host, (size_t)D * 16, hipMemcpyHostToDevice, stream));
@@ -461,6 +508,10 @@ public:
             feats_stage.ensure((size_t)D * EMB);
             YDS_HIP(hipMemcpyAsync(feats_stage.p, feats, (size_t)D * EMB * 4, hipMemcpyHostToDevice, stream));
             feats_dev = feats_stage.p;
+        }
+        if (D) {                                              // x / ||x|| once per frame (nn_matching.py:50-52)
+            feats_n.ensure((size_t)D * EMB);
+            hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, stream, feats_dev, (const int *)nullptr, feats_n.p, D);
         }
         // ---- Tracker.predict (tracker.py:95-113)
         if (T) {
@@ -484,7 +535,7 @@ public:
             for (int r = 0; r < Tc; ++r) { slots[r] = tracks[confirmed[r]].slot; rows[r] = tracks[confirmed[r]].n_feat; }
             cost_dev.ensure((size_t)Tc * D);
             hipLaunchKernelGGL(appearance_cost_kernel, dim3(Tc, (D + 15) / 16), dim3(256), 0, stream, gallery.p, up(slots), up(rows), budget,
-                               feats_dev, up(all_dets), D, mean.p, cov.p, tlwh_dev.p, (float)max_dist, (float)(max_dist + 1e-5), 1, cost_dev.p);
+                               feats_n.p, D, mean.p, cov.p, tlwh_dev.p, (float)max_dist, (float)(max_dist + 1e-5), 1, cost_dev.p);
             Assignment a;
             solve(cost_dev.p, Tc, D, a);
             bookkeeping(a, D, (float)max_dist, confirmed, all_dets, matches, um_t_a, um_d);
@@ -530,7 +581,7 @@ public:
             const int *dslots = up(slots), *ddets = up(dets);
             hipLaunchKernelGGL(tlwh_to_xyah_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, tlwh_dev.p, ddets, z_dev.p, M);
             hipLaunchKernelGGL(kf_update_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, mean.p, cov.p, dslots, z_dev.p, M);
-            hipLaunchKernelGGL(feature_append_kernel, dim3(M), dim3(128), 0, stream, gallery.p, budget, dslots, up(pos), feats_dev, ddets, M);
+            hipLaunchKernelGGL(feature_append_kernel, dim3(M), dim3(128), 0, stream, gallery.p, budget, dslots, up(pos), feats_n.p, ddets, M);
         }
         for (int k : unmatched_tracks) {                                   // Track.mark_missed track.py:146-152
             Track &t = tracks[k];
@@ -552,7 +603,7 @@ public:
             }
             const int *dslots = up(slots), *ddets = up(um_d);
             hipLaunchKernelGGL(kf_initiate_kernel, dim3((Nn + 63) / 64), dim3(64), 0, stream, mean.p, cov.p, dslots, tlwh_dev.p, ddets, Nn);
-            hipLaunchKernelGGL(feature_append_kernel, dim3(Nn), dim3(128), 0, stream, gallery.p, budget, dslots, up(pos), feats_dev, ddets, Nn);
+            hipLaunchKernelGGL(feature_append_kernel, dim3(Nn), dim3(128), 0, stream, gallery.p, budget, dslots, up(pos), feats_n.p, ddets, Nn);
         }
         std::vector<Track> alive;
         for (const Track &t : tracks) {
@@ -583,10 +634,11 @@ public:
     int capacity = 0, next_id = 1;
     std::vector<Track> tracks;
     std::vector<int> free_slots;
-    DevBuf<float> mean, cov, gallery, tlwh_dev, feats_stage, cost_dev, z_dev, pl_dev;
-    DevBuf<int> lsap_rows, lsap_cols, ibuf, out_dev;
+    DevBuf<float> mean, cov, gallery /* rows stored normalised */, tlwh_dev, feats_stage, feats_n, cost_dev, z_dev, pl_dev;
+    DevBuf<int> lsap_rows, lsap_cols, out_dev;
+    static constexpr size_t IBUF_INTS = 1 << 16;
+    int *ibuf_host = nullptr, *ibuf_dev = nullptr;
     size_t ibuf_used = 0;
-    std::vector<std::vector<int>> keep_alive;
     std::vector<std::pair<int, int>> last_matches;
     std::vector<int> last_um_t, last_um_d;
     hipStream_t stream = nullptr;
@@ -676,8 +728,7 @@ int yds_lsap(const float *cost_host, int nr, int nc, int32_t *rows, int32_t *col
     hipStream_t s = g_scratch.stream();
     DevBuf<float> c; c.upload(cost_host, (size_t)nr * nc, s);
     DevBuf<int> r(n), cc(n);
-    hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(64), 0, s, c.p, nr, nc, r.p, cc.p);
-    YDS_HIP(hipGetLastError());
+    launch_lsap(c.p, nr, nc, r.p, cc.p, s);
     YDS_HIP(hipMemcpyAsync(rows, r.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
     YDS_HIP(hipMemcpyAsync(cols, cc.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
@@ -758,11 +809,13 @@ int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_ho
         rows[t] = seg_offsets_host[t + 1] - seg_offsets_host[t];
         memcpy(&g[(size_t)t * budget * EMB], gallery_host + (size_t)seg_offsets_host[t] * EMB, (size_t)rows[t] * EMB * 4);
     }
-    DevBuf<float> gd, fd, o((size_t)T * D); DevBuf<int> sl, nr, di;
+    DevBuf<float> gd, fd, gn(g.size()), fn((size_t)D * EMB), o((size_t)T * D); DevBuf<int> sl, nr;
     gd.upload(g.data(), g.size(), s); fd.upload(feats_host, (size_t)D * EMB, s);
     auto v = iota(T); sl.upload(v.data(), T, s); nr.upload(rows.data(), T, s);
-    auto w = iota(D); di.upload(w.data(), D, s);
-    hipLaunchKernelGGL(appearance_cost_kernel, dim3(T, (D + 15) / 16), dim3(256), 0, s, gd.p, sl.p, nr.p, budget, fd.p, di.p, D,
+    const int G = T * budget;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((G + 3) / 4), dim3(256), 0, s, gd.p, (const int *)nullptr, gn.p, G);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, s, fd.p, (const int *)nullptr, fn.p, D);
+    hipLaunchKernelGGL(appearance_cost_kernel, dim3(T, (D + 15) / 16), dim3(256), 0, s, gn.p, sl.p, nr.p, budget, fn.p, D,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, 0.f, 0, o.p);
     YDS_HIP(hipMemcpyAsync(out, o.p, (size_t)T * D * 4, hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
