@@ -488,7 +488,55 @@ def gen_track_traces(ns):
     _save("track_trace_200x150", **_pack_trace(rec))
 
 
-ALL = dict(cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
+def gen_tiled(ns):
+    """8f row 1: tiled sliding-window detection + the merge=True NMS branch as it really behaves."""
+    import contextlib
+    import io
+    import torch
+    cfg = cfgs.cfg_text("yolov3-tiny")
+    names = _tmp_write(cfgs.coco_names_text(), ".names")
+    frame = np.random.RandomState(0).randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    arrays = {}
+    # -1.3: some boxes suppressed (plain NMS stands); -1.4: nothing suppressed -> every box collapses (here onto NaN:
+    # the elementwise IoU of score-ordered vs original-ordered boxes is 0 everywhere, so the weights sum to 0)
+    for tag, ob in (("a", -1.3), ("b", -1.4)):
+        model, torch = _ref_darknet(ns, cfg, (416, 416), seed=0, obj_bias=ob)
+        det = ns.img_detect.ImageDetector(model, names, thres=0.5, nms_thres=0.4, win_size=(416, 416), overlap=0.15)
+        with contextlib.redirect_stdout(io.StringIO()):        # the reference prints tensors from its bare except
+            out = det.detect(frame)
+        print(f"    tiled obj_bias {ob}: {0 if out is None else out.shape[0]} detections")
+        arrays["tiled_out_" + tag] = out.numpy() if out is not None else np.zeros((0, 6), F32)
+        arrays["obj_bias_" + tag] = np.array(ob)
+    os.unlink(names)
+    # merge branch unit cases on corner-form predictions
+    rng = np.random.RandomState(33)
+
+    def pred_of(boxes, n=60):
+        p = np.zeros((1, n, 85), F32)
+        p[0, :, 4] = 0.01
+        for k, (x1, y1, x2, y2, c, obj, cls) in enumerate(boxes):
+            p[0, k * 3, :4] = (x1, y1, x2, y2)
+            p[0, k * 3, 4] = obj
+            p[0, k * 3, 5 + c] = cls
+        return p
+    cases = {
+        "all_kept": pred_of([(10, 10, 60, 80, 0, .9, .95), (200, 50, 260, 150, 2, .8, .95), (400, 300, 470, 420, 0, .7, .95)]),
+        "one_kept": pred_of([(100, 100, 200, 220, 0, .9, .95), (104, 98, 205, 226, 0, .8, .9), (96, 103, 196, 215, 0, .7, .92),
+                             (101, 101, 199, 219, 0, .85, .6)]),
+        "plain": pred_of([(100, 100, 200, 220, 0, .9, .95), (104, 98, 205, 226, 0, .8, .9), (400, 300, 470, 420, 0, .7, .95),
+                          (402, 301, 468, 424, 0, .75, .9), (20, 20, 50, 60, 4, .9, .9)]),
+        "single": pred_of([(10, 10, 60, 80, 0, .9, .95)]),
+    }
+    for name, p in cases.items():
+        with contextlib.redirect_stdout(io.StringIO()):
+            o = ns.model_build.soft_non_max_suppression(torch.from_numpy(p.copy()), 0.5, 0.4, merge=True, is_p1p2=True)[0]
+        arrays[name + "_pred"] = p
+        arrays[name + "_out"] = o.numpy() if o is not None else np.zeros((0, 6), F32)
+        print(f"    merge {name}: {arrays[name + '_out'].shape[0]} rows")
+    _save("tiled_detect", **arrays)
+
+
+ALL = dict(tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
            nms=gen_nms, plumbing=gen_detect_plumbing, reid=gen_reid, kalman=gen_kalman,
            traces=gen_track_traces)
 

@@ -92,3 +92,49 @@ def p1p2_to_xywh(x):
     y[..., 2] = x[..., 2] - x[..., 0]
     y[..., 3] = x[..., 3] - x[..., 1]
     return y
+
+
+def bbox_iou_plus1(b1, b2, eps=1e-16):
+    """model_build.py:354-381 (p1p2 form): elementwise IoU with the +1 pixel convention, fp32."""
+    imin = np.maximum(b1[..., :2], b2[..., :2])
+    imax = np.minimum(b1[..., 2:4], b2[..., 2:4])
+    wh = np.maximum((imax - imin + F32(1)).astype(F32), F32(0))
+    inter = (wh[..., 0] * wh[..., 1]).astype(F32)
+    a1 = ((b1[..., 2] - b1[..., 0] + F32(1)) * (b1[..., 3] - b1[..., 1] + F32(1))).astype(F32)
+    a2 = ((b2[..., 2] - b2[..., 0] + F32(1)) * (b2[..., 3] - b2[..., 1] + F32(1))).astype(F32)
+    return (inter / ((a1 + a2).astype(F32) - inter + F32(eps)).astype(F32)).astype(F32)
+
+
+def soft_non_max_suppression_merge(prediction, conf_thres, iou_thres, is_p1p2=True):
+    """soft_non_max_suppression(..., merge=True) as the reference actually behaves (model_build.py:122-131).
+
+    `bbox_iou(boxes[i], boxes)` is elementwise, not pairwise: it only broadcasts when the number of kept boxes k is 1
+    or equals the number of candidates n; otherwise it raises inside the bare `except` and the plain NMS result
+    stands.  When it does broadcast, x[i, :4] is overwritten with ONE weighted-mean box (weights = score where the
+    elementwise IoU exceeds the threshold) before `iou.sum(1)` raises - so a lone survivor becomes the mean of its
+    cluster and, when nothing was suppressed, every box collapses onto the same mean.  Reproduced, not fixed."""
+    prediction = np.asarray(prediction, dtype=F32)
+    ct = F32(conf_thres)
+    out = [None] * prediction.shape[0]
+    for xi in range(prediction.shape[0]):
+        x = prediction[xi][prediction[xi][:, 4] > ct].copy()
+        if not x.shape[0]:
+            continue
+        x[:, 5:] *= x[:, 4:5]
+        box = x[:, :4] if is_p1p2 else xywh2p1p2(x[:, :4])
+        i, j = np.nonzero(x[:, 5:] > ct)
+        x = np.concatenate((box[i], x[i, j + 5, None], j[:, None].astype(F32)), 1).astype(F32)
+        n = x.shape[0]
+        if not n:
+            continue
+        c = (x[:, 5:6] * F32(4096)).astype(F32)
+        boxes, scores = (x[:, :4] + c).astype(F32), x[:, 4]
+        k = nms_greedy(boxes, scores, iou_thres)[:300]
+        if 1 < n < 3000 and (len(k) == n or len(k) == 1):
+            iou = bbox_iou_plus1(boxes[k], boxes) > F32(iou_thres)            # [n] bools (broadcast of [k,4] with [n,4])
+            w = (iou.astype(F32) * scores).astype(F32)[None, :]                  # [1,n]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                merged = ((w @ x[:, :4]).astype(F32) / w.sum(1, keepdims=True, dtype=F32)).astype(F32)
+            x[k, :4] = merged
+        out[xi] = x[k]
+    return out

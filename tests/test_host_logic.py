@@ -157,3 +157,30 @@ r.shutdown()
     finally:
         os.unlink(f.name)
     assert out.returncode == 0 and "OK 80.0" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
+
+
+def test_save_darknet_weights_layout_roundtrip():
+    """save_darknet_weights re-emits the loaded stream (reference models.py:368-394); checked on the host-side
+    float accounting with the oracle's reader (no GPU needed: the engine is not touched)."""
+    from oracle.darknet import DarknetOracle
+    from yolo_deepsort_amd.models import Darknet
+    text = cfgs.cfg_text("yolov3-tiny")
+    blob = synth.darknet_weights_blob(text, 3)
+    net = Darknet.__new__(Darknet)                      # host-only skeleton: no device handle
+    net.cfg_text, net._weights_blob, net.seen = text, blob, 7
+    net.header_info = np.frombuffer(blob[:20], dtype=np.int32).copy()
+    net.module_defs = loaders.parse_model_config(None, text=text)[1:]
+    net._h = None
+    with tempfile.NamedTemporaryFile(suffix=".weights", delete=False) as f:
+        pass
+    try:
+        net.save_darknet_weights(f.name)
+        back = open(f.name, "rb").read()
+        assert back[20:] == blob[20:] and np.frombuffer(back[:20], np.int32)[3] == 7
+        net.save_darknet_weights(f.name, cutoff=13)      # backbone only, like darknet53.conv.74 style cut-offs
+        part = open(f.name, "rb").read()
+        ref = DarknetOracle(text, 416, is_text=True)
+        used = ref.load_weights_array(np.frombuffer(blob, dtype=np.float32, offset=20), cutoff=13)
+        assert len(part) == 20 + used * 4 and part[20:] == blob[20:20 + used * 4]
+    finally:
+        os.unlink(f.name)

@@ -120,3 +120,25 @@ def test_real_cfg_files_parse_identically():
         mine = parse_model_config_text(text)
         red = [{k: v for k, v in d.items() if k in ref[name][i]} for i, d in enumerate(mine)]
         assert red == ref[name]
+
+
+def test_tiled_detection_and_merge_quirk():
+    """8f row 1: sliding-window detection; the merge=True branch collapses boxes exactly like the reference."""
+    from oracle.tiled import detect_tiled
+    g = golden("tiled_detect")
+    for name in ("all_kept", "one_kept", "plain", "single"):
+        out = onms.soft_non_max_suppression_merge(g[name + "_pred"], 0.5, 0.4, is_p1p2=True)[0]
+        ref = g[name + "_out"]
+        assert out.shape == ref.shape, name
+        assert np.array_equal(out[:, 4:], ref[:, 4:]), name
+        np.testing.assert_allclose(out[:, :4], ref[:, :4], rtol=1e-6, atol=1e-4, err_msg=name)
+    assert np.ptp(g["all_kept_out"][:, 0]) == 0            # the collapse really happened in the reference
+    frame = np.random.RandomState(0).randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    for tag in ("a", "b"):
+        net = _oracle_net(cfgs.cfg_text("yolov3-tiny"), 416, 0, float(g["obj_bias_" + tag]))
+        det = detect_tiled(net, frame, (416, 416), 0.15, 0.5, 0.4)
+        ref = g["tiled_out_" + tag]
+        assert det.shape == ref.shape and ref.shape[0] > 3
+        assert np.array_equal(det[:, 5], ref[:, 5])
+        np.testing.assert_allclose(det, ref, rtol=RTOL, atol=ATOL, equal_nan=True)
+    assert np.isnan(g["tiled_out_b"][:, :4]).all() and not np.isnan(g["tiled_out_a"]).any()

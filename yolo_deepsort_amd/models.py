@@ -77,6 +77,27 @@ class Darknet:
         self._weights_blob = bytes(blob)
         _lib.check(_lib.load().yds_darknet_load_weights(self._h, self._weights_blob, len(blob), self._cutoff))
 
+    def save_darknet_weights(self, path, cutoff=-1):
+        """models.py:368-394: header (with ``seen``) then, per conv block up to ``cutoff``, [beta, gamma, mean, var]
+        or [bias] and the weights.  The engine keeps the loaded file image, so saving re-emits exactly the floats
+        that were loaded (inference never changes them)."""
+        blob = getattr(self, "_weights_blob", None)
+        if blob is None:
+            raise RuntimeError("no weights loaded")
+        from .synth import conv_shapes
+        n_blocks = len(self.module_defs)
+        stop = n_blocks if cutoff == -1 else (cutoff if cutoff >= 0 else n_blocks + cutoff)
+        header = np.array(self.header_info, dtype=np.int32).copy()
+        header[3] = self.seen
+        floats = 0
+        for idx, cin, cout, k, bn, _, _ in conv_shapes(self.cfg_text):
+            if idx >= stop:
+                break
+            floats += (4 if bn else 1) * cout + cout * cin * k * k
+        with open(path, "wb") as f:
+            f.write(header.tobytes())
+            f.write(blob[20:20 + floats * 4])
+
     def to(self, device):
         self.device = str(device)
         return self
