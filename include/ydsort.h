@@ -90,6 +90,20 @@ int yds_nms(yds_net *, int image, float conf_thres, float iou_thres, int frame_h
 int yds_nms_pred(const float *pred_host, int n_boxes, int attrs, float conf_thres, float iou_thres,
                  float *out6_host, int cap, int *n_out);
 
+/* ---- sliding-window detection ----------------------------------------
+ * yds_detect_tiled    <- ImageDetector.detect win_size branch  yolo3/detect/img_detect.py:97-151: every window
+ *                        (x, y, tile_h, tile_w) of the host frame is stretched to the model size, the windows run as
+ *                        batches, boxes go to corner form, are scaled to the window (resize_boxes) and shifted by its
+ *                        origin, and the concatenation passes through soft_non_max_suppression(merge=True,
+ *                        is_p1p2=True).  The caller cuts the windows (host loop :103-121).
+ * yds_nms_merge_pred  <- soft_non_max_suppression(merge=True, is_p1p2=True) model_build.py:52-137 on host predictions
+ *                        in corner form.  The merge branch is reproduced as it behaves, not as it was meant: it only
+ *                        takes effect when 1 or all candidates survive, see DESIGN.md. */
+int yds_detect_tiled(yds_net *, const uint8_t *rgb_hwc_host, int h, int w, const int32_t *tiles_xyhw, int n_tiles,
+                     float conf_thres, float iou_thres, float *out6_host, int cap, int *n_out);
+int yds_nms_merge_pred(const float *pred_host, int n_boxes, int attrs, float conf_thres, float iou_thres,
+                       float *out6_host, int cap, int *n_out);
+
 /* ---- ReID: crop + Extractor + Net(reid=True) --------------------------------------------
  * yds_reid_load_tensor <- Extractor.__init__ load_state_dict  feature_extractor.py:13-17
  *                         (one call per 'net_dict' entry; names as in deep_sort/deep/model.py)

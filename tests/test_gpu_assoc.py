@@ -89,6 +89,113 @@ def test_detect_plumbing_cfg1_golden():
     assert det.detect(np.zeros((480, 640, 3), np.uint8)) is None or True
 
 
+def _nms_merge(pred, ct, it):
+    L = _lib()
+    pred = np.ascontiguousarray(pred, dtype=F32)
+    out = np.zeros((300, 6), F32)
+    n = C.c_int(0)
+    L.check(L.load().yds_nms_merge_pred(L.ptr(pred), pred.shape[0], pred.shape[1], ct, it, L.ptr(out), 300, C.byref(n)))
+    return out[:n.value]
+
+
+def test_nms_merge_branch_golden_and_oracle():
+    """soft_non_max_suppression(merge=True, is_p1p2=True): ids/scores bit-exact, merged boxes within 1e-4 px."""
+    from oracle import nms as onms
+    g = golden("tiled_detect")
+    for nme in ("all_kept", "one_kept", "plain", "single"):
+        got = _nms_merge(g[nme + "_pred"][0], 0.5, 0.4)
+        ref = g[nme + "_out"]
+        assert got.shape == ref.shape, nme
+        assert np.array_equal(got[:, 4:], ref[:, 4:]), nme
+        np.testing.assert_allclose(got[:, :4], ref[:, :4], rtol=1e-6, atol=1e-4, err_msg=nme)
+    rng = np.random.RandomState(8)
+    seen = set()
+    for trial in range(40):
+        n = int(rng.choice([2, 3, 5, 40]))
+        p = np.zeros((1, n, 85), F32)
+        if trial % 2:                                   # one tight cluster -> a single survivor
+            p[0, :, :2] = 300 + rng.uniform(-3, 3, (n, 2))
+            p[0, :, 2:4] = p[0, :, :2] + 120 + rng.uniform(-3, 3, (n, 2))
+        else:
+            p[0, :, :2] = rng.uniform(0, 1500, (n, 2))
+            p[0, :, 2:4] = p[0, :, :2] + rng.uniform(5, 60, (n, 2))
+        p[0, :, 4] = rng.uniform(0.3, 1, n)
+        p[0, np.arange(n), 5 + (0 if trial % 2 else rng.randint(0, 3, n))] = rng.uniform(0.6, 1, n)
+        want = onms.soft_non_max_suppression_merge(p, 0.5, 0.4)[0]
+        got = _nms_merge(p[0], 0.5, 0.4)
+        if want is None:
+            assert got.shape[0] == 0
+            continue
+        assert got.shape == want.shape, trial
+        assert np.array_equal(got[:, 4:], want[:, 4:]), trial
+        assert np.array_equal(np.isnan(got), np.isnan(want)), trial
+        np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=1e-6, atol=1e-3, equal_nan=True, err_msg=str(trial))
+        b = p[..., :4].astype(np.float64)
+        centre = np.stack([(b[..., 0] + b[..., 2]) / 2, (b[..., 1] + b[..., 3]) / 2, b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]], -1)
+        plain = onms.soft_non_max_suppression(np.concatenate([centre.astype(F32), p[..., 4:]], -1), 0.5, 0.4)[0]
+        seen.add("merged" if not np.allclose(np.nan_to_num(want[:, :4]), plain[:, :4], atol=1e-3) else "plain")
+    assert seen == {"merged", "plain"}
+
+
+def _tiled_detector(obj_bias, batch_max):
+    import os
+    import tempfile
+    from yolo_deepsort_amd import cfgs
+    from yolo_deepsort_amd.detect import ImageDetector
+    from yolo_deepsort_amd.models import Darknet
+    cfg = cfgs.cfg_text("yolov3-tiny")
+    net = Darknet(None, img_size=(416, 416), cfg_text=cfg, batch_max=batch_max)
+    net.load_darknet_weights(None, blob=synth.darknet_weights_blob(cfg, 0, obj_bias))
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+    det = ImageDetector(net, f.name, thres=0.5, nms_thres=0.4, win_size=(416, 416), overlap=0.15)
+    os.unlink(f.name)
+    return det
+
+
+def test_tiled_detection_golden():
+    """ImageDetector(win_size=...) on a 640x480 frame = 4 windows, vs the reference's own output."""
+    g = golden("tiled_detect")
+    frame = np.random.RandomState(0).randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    for tag in ("a", "b"):
+        ref = g["tiled_out_" + tag]
+        outs = []
+        for batch_max in (4, 3, 1):                       # windows in one batch, and in chunks
+            out = _tiled_detector(float(g["obj_bias_" + tag]), batch_max).detect(frame)
+            out = out.numpy() if hasattr(out, "numpy") else out
+            assert out.shape == ref.shape, (tag, batch_max)
+            assert np.array_equal(out[:, 5], ref[:, 5])
+            np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL, equal_nan=True)
+            outs.append(out)
+        assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
+    # a frame smaller than the window takes the plain path (img_detect.py:67)
+    small = np.random.RandomState(1).randint(0, 256, (300, 400, 3)).astype(np.uint8)
+    det = _tiled_detector(-1.3, 1)
+    a = det.detect(small)
+    det.win_size = None
+    b = det.detect(small)
+    assert (a is None and b is None) or np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_tiled_detection_vs_oracle_odd_frame():
+    """ragged windows (frame not a multiple of win_size, windows clipped at the border) vs the oracle."""
+    from oracle.darknet import DarknetOracle
+    from oracle.tiled import detect_tiled, windows
+    from yolo_deepsort_amd import cfgs
+    cfg = cfgs.cfg_text("yolov3-tiny")
+    ob = -1.3
+    frame = np.random.RandomState(4).randint(0, 256, (531, 977, 3)).astype(np.uint8)
+    assert len(windows(531, 977, (416, 416), 0.15)) == 6
+    ref = DarknetOracle(cfg, 416, is_text=True)
+    ref.load_weights_array(np.frombuffer(synth.darknet_weights_blob(cfg, 0, ob), dtype=F32, offset=20))
+    want = detect_tiled(ref, frame, (416, 416), 0.15, 0.5, 0.4)
+    out = _tiled_detector(ob, 4).detect(frame)
+    out = out.numpy() if hasattr(out, "numpy") else out
+    assert want is not None and out.shape == want.shape
+    assert np.array_equal(out[:, 5], want[:, 5])
+    np.testing.assert_allclose(out, want, rtol=RTOL, atol=ATOL, equal_nan=True)
+
+
 # ----------------------------------------------------------------------------------------- ReID
 def test_reid_golden_and_oracle():
     from oracle import reid as oreid

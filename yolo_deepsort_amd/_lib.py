@@ -59,6 +59,8 @@ SIGNATURES = {
     "yds_conv_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "yds_nms": (_I, [_P, _I, _F, _F, _I, _I, _P, _I, _P]),
     "yds_nms_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),
+    "yds_nms_merge_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),
+    "yds_detect_tiled": (_I, [_P, _P, _I, _I, _P, _I, _F, _F, _P, _I, _P]),
     "yds_reid_create": (_P, [_I]),
     "yds_reid_destroy": (None, [_P]),
     "yds_reid_load_tensor": (_I, [_P, C.c_char_p, _P, _P, _I]),

@@ -117,6 +117,9 @@ void launch_inject(const View &head, int image, const float *rows_dev, int n, in
                    float logit, hipStream_t s);
 // stretch-resize uint8 HWC frames to NHWC4 fp32 in [0,1] (4th channel 0)
 void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s);
+void launch_tile_resize(const uint8_t *frame, int w, const int *tiles_dev, int n_tiles, const View &y, hipStream_t s);
+void launch_tile_boxes(const float *pred, int n_boxes, int attrs, const int *tiles_dev, const float *scale_dev, int n_tiles, float *dst,
+                       hipStream_t s);
 // ReID: crop + resize to 64x128 + /255 + mean/std -> NHWC4
 // boxes: [D,5] = x1,y1,x2,y2,frame index (frames are h*w*3 bytes apart)
 void launch_crop_resize(const uint8_t *frames, int h, int w, const int *boxes5_dev, int D, const View &y,

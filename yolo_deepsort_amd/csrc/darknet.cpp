@@ -464,6 +464,34 @@ void Darknet::forward_u8_host(const uint8_t *frames, int h, int w, int batch, fl
     YDS_HIP(hipStreamSynchronize(stream));
 }
 
+void Darknet::forward_tiles_host(const uint8_t *frame, int h, int w, const int *tiles, int n_tiles) {
+    if (in_channels != 3) fail("forward_tiles: network expects %d channels", in_channels);
+    if (n_tiles < 1) fail("forward_tiles: no windows");
+    std::vector<float> scale((size_t)n_tiles * 2);
+    for (int t = 0; t < n_tiles; ++t) {
+        const int x = tiles[t * 4], y = tiles[t * 4 + 1], th = tiles[t * 4 + 2], tw = tiles[t * 4 + 3];
+        if (x < 0 || y < 0 || th < 1 || tw < 1 || x + tw > w || y + th > h) fail("forward_tiles: window %d (%d,%d,%d,%d) outside the %dx%d frame", t, x, y, th, tw, w, h);
+        scale[t * 2] = (float)((double)tw / img_w);            // resize_boxes: python-double ratio, fp32 multiply
+        scale[t * 2 + 1] = (float)((double)th / img_h);
+    }
+    const size_t nbytes = (size_t)h * w * 3;
+    stage_u8.ensure(nbytes);
+    tile_rects.ensure((size_t)n_tiles * 4);
+    tile_scale.ensure((size_t)n_tiles * 2);
+    tiled_pred.ensure((size_t)n_tiles * total_boxes * attrs);
+    YDS_HIP(hipMemcpyAsync(stage_u8.p, frame, nbytes, hipMemcpyHostToDevice, stream));
+    YDS_HIP(hipMemcpyAsync(tile_rects.p, tiles, (size_t)n_tiles * 4 * sizeof(int), hipMemcpyHostToDevice, stream));
+    YDS_HIP(hipMemcpyAsync(tile_scale.p, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    for (int t0 = 0; t0 < n_tiles; t0 += batch_max) {
+        const int nb = std::min(batch_max, n_tiles - t0);
+        launch_tile_resize(stage_u8.p, w, tile_rects.p + (size_t)t0 * 4, nb, input_view(nb), stream);
+        run_graph(nb);
+        launch_tile_boxes(out.p, total_boxes, attrs, tile_rects.p + (size_t)t0 * 4, tile_scale.p + (size_t)t0 * 2, nb,
+                          tiled_pred.p + (size_t)t0 * total_boxes * attrs, stream);
+    }
+    YDS_HIP(hipStreamSynchronize(stream));          // `scale` and the caller's buffers may go away
+}
+
 void Darknet::layer_output_host(int i, int batch, float *nchw) {
     if (i < 0 || i >= (int)layers.size()) fail("layer_output: no layer %d", i);
     const Layer &l = layers[i];

@@ -56,6 +56,9 @@ public:
     void forward_u8_host(const uint8_t *frames, int h, int w, int batch, float *out_host);
     void forward_u8_dev(const uint8_t *frames_dev, int h, int w, int batch);
     void forward_resized(int batch) { run_graph(batch); }      // input buffer already filled
+    // sliding-window front end (img_detect.py:97-139): windows (x, y, th, tw) of one host frame -> corner-form, window-
+    // shifted predictions [n_tiles * total_boxes, attrs] in tiled_pred (windows run in chunks of batch_max)
+    void forward_tiles_host(const uint8_t *frame, int h, int w, const int *tiles_xyhw, int n_tiles);
     void layer_output_host(int layer, int batch, float *nchw);
     void get_input_host(int batch, float *nchw);
     void set_injection(int image, const float *rows, int n, float logit);
@@ -77,6 +80,8 @@ public:
     std::vector<int> yolo_layers;
     DevBuf<float> input, out, stage_f32;
     DevBuf<uint8_t> stage_u8;
+    DevBuf<float> tiled_pred, tile_scale;
+    DevBuf<int> tile_rects;
     hipStream_t stream = nullptr;
     int32_t header[5] = {0, 0, 0, 0, 0};
     bool weights_loaded = false;
@@ -115,7 +120,10 @@ public:
     // scaled by (sx, sy) when scale is requested (resize_boxes).
     int run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
             float *out6_host, int cap, hipStream_t s);
+    // merge=True / is_p1p2=True form used by the sliding-window detector: corner-form boxes, the reference's merge branch
+    int run_merge(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float *out6_host, int cap, hipStream_t s);
     int max_cand, frames;
+    bool corner = false;         // predictions already hold x1,y1,x2,y2
     DevBuf<float> cand;          // [max_cand, 6]   x1,y1,x2,y2,score,cls in candidate order
     DevBuf<float> sorted;        // [max_cand, 6]   score order
     DevBuf<int> counts;          // [0] n candidates, [1] n kept

@@ -327,6 +327,60 @@ void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y,
     YDS_HIP(hipGetLastError());
 }
 
+// Sliding-window front end (img_detect.py:103-111): window `b` of the frame (x, y, th, tw) is stretched to the model
+// size into batch slot b, same bilinear arithmetic as resize_u8_kernel.
+__global__ void tile_resize_kernel(const uint8_t *frame, int W, const int *tiles, int n_tiles, float *y, int Ho, int Wo) {
+    const size_t total = (size_t)n_tiles * Ho * Wo;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        int ox = idx % Wo;
+        size_t t = idx / Wo;
+        int oy = t % Ho;
+        int n = t / Ho;
+        const int x0 = tiles[n * 4 + 0], y0 = tiles[n * 4 + 1], th = tiles[n * 4 + 2], tw = tiles[n * 4 + 3];
+        const float sx = __fdiv_rn((float)tw, (float)Wo), sy = __fdiv_rn((float)th, (float)Ho);
+        Tap tx = axis_tap(ox, sx, tw), ty = axis_tap(oy, sy, th);
+        const uint8_t *r0 = frame + ((size_t)(y0 + ty.i0) * W + x0) * 3, *r1 = frame + ((size_t)(y0 + ty.i1) * W + x0) * 3;
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = lerp2(r0[tx.i0 * 3 + c], r0[tx.i1 * 3 + c], r1[tx.i0 * 3 + c], r1[tx.i1 * 3 + c], tx.f, ty.f);
+            o[c] = __fdiv_rn(v, 255.f);
+        }
+        o[3] = 0.f;
+        *reinterpret_cast<float4 *>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+void launch_tile_resize(const uint8_t *frame, int w, const int *tiles_dev, int n_tiles, const View &y, hipStream_t s) {
+    if (y.c != 4 || y.ld != 4) fail("resize: destination must be NHWC4");
+    hipLaunchKernelGGL(tile_resize_kernel, dim3(grid_for((size_t)n_tiles * y.h * y.w)), dim3(256), 0, s, frame, w, tiles_dev, n_tiles, y.p, y.h, y.w);
+    YDS_HIP(hipGetLastError());
+}
+
+// img_detect.py:131-139: centre form -> corner form (x -+ w/2), resize_boxes to the window's own size (python-double
+// ratio rounded to fp32, passed in `scale`), shift by the window origin; the other attributes are copied.
+__global__ void tile_boxes_kernel(const float *pred, int n_boxes, int attrs, const int *tiles, const float *scale, int n_tiles, float *dst) {
+    const size_t total = (size_t)n_tiles * n_boxes;
+    for (size_t row = blockIdx.x * (size_t)(blockDim.x / 32) + threadIdx.x / 32; row < total; row += (size_t)gridDim.x * (blockDim.x / 32)) {
+        const int b = row / n_boxes, lane = threadIdx.x % 32;
+        const float *p = pred + row * attrs;
+        float *d = dst + row * attrs;
+        for (int j = 4 + lane; j < attrs; j += 32) d[j] = p[j];
+        if (lane < 4) {
+            const float half = __fdiv_rn(p[2 + (lane & 1)], 2.f);
+            float v = lane < 2 ? __fsub_rn(p[lane & 1], half) : __fadd_rn(p[lane & 1], half);
+            v = __fmul_rn(v, scale[b * 2 + (lane & 1)]);
+            d[lane] = __fadd_rn(v, (float)tiles[b * 4 + (lane & 1)]);
+        }
+    }
+}
+
+void launch_tile_boxes(const float *pred, int n_boxes, int attrs, const int *tiles_dev, const float *scale_dev, int n_tiles, float *dst, hipStream_t s) {
+    hipLaunchKernelGGL(tile_boxes_kernel, dim3(grid_for((size_t)n_tiles * n_boxes * 32)), dim3(256), 0, s, pred, n_boxes, attrs, tiles_dev, scale_dev,
+                       n_tiles, dst);
+    YDS_HIP(hipGetLastError());
+}
+
 __global__ void crop_resize_kernel(const uint8_t *frames, int H, int W, const int *boxes, int D, float *y, int Ho, int Wo) {
     const size_t total = (size_t)D * Ho * Wo;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {

@@ -19,6 +19,9 @@
 
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 namespace yds {
 
 constexpr int MAX_DET = 300;
@@ -68,7 +71,7 @@ __global__ void nms_scan_kernel(int *box_count_all, int n_boxes, int *counts_all
 }
 
 __global__ void nms_emit_kernel(const float *pred_all, size_t pred_stride, int n_boxes, int attrs, float thr, const int *box_off_all, int max_cand,
-                                float *cand_all) {
+                                float *cand_all, int corner) {
     const float *pred = pred_all + blockIdx.y * pred_stride;
     const int *box_off = box_off_all + (size_t)blockIdx.y * n_boxes;
     float *cand = cand_all + (size_t)blockIdx.y * max_cand * 6;
@@ -78,8 +81,11 @@ __global__ void nms_emit_kernel(const float *pred_all, size_t pred_stride, int n
     float obj = p[4];
     if (!(obj > thr)) return;
     int slot = box_off[i];
-    float hw = __fdiv_rn(p[2], 2.f), hh = __fdiv_rn(p[3], 2.f);
-    float x1 = __fsub_rn(p[0], hw), y1 = __fsub_rn(p[1], hh), x2 = __fadd_rn(p[0], hw), y2 = __fadd_rn(p[1], hh);
+    float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];           // is_p1p2=True: boxes arrive in corner form
+    if (!corner) {
+        float hw = __fdiv_rn(p[2], 2.f), hh = __fdiv_rn(p[3], 2.f);
+        x1 = __fsub_rn(p[0], hw); y1 = __fsub_rn(p[1], hh); x2 = __fadd_rn(p[0], hw); y2 = __fadd_rn(p[1], hh);
+    }
     for (int j = 5; j < attrs; ++j) {
         float sc = __fmul_rn(p[j], obj);
         if (sc > thr) {
@@ -219,7 +225,7 @@ void NmsWorkspace::launch(const float *pred_dev, size_t pred_stride, int n_frame
     hipLaunchKernelGGL(nms_count_kernel, dim3(nb, n_frames), dim3(256), 0, s, pred_dev, pred_stride, n_boxes, attrs, conf_thres, box_count.p);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1, n_frames), dim3(1024), 0, s, box_count.p, n_boxes, counts.p);
     hipLaunchKernelGGL(nms_emit_kernel, dim3(nb, n_frames), dim3(256), 0, s, pred_dev, pred_stride, n_boxes, attrs, conf_thres, box_count.p,
-                       max_cand, cand.p);
+                       max_cand, cand.p, corner ? 1 : 0);
     hipLaunchKernelGGL(nms_rank_kernel, dim3(16, n_frames), dim3(256), 0, s, cand.p, counts.p, max_cand, sorted.p);
     const int words_ld = max_cand / 64;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(64, n_frames), dim3(256), 0, s, sorted.p, counts.p, max_cand, (double)iou_thres, mask.p, words_ld);
@@ -246,6 +252,55 @@ int NmsWorkspace::run(const float *pred_dev, int n_boxes, int attrs, float conf_
     return collect(0, out6_host, cap);
 }
 
+// soft_non_max_suppression(merge=True, is_p1p2=True) as the reference behaves (model_build.py:122-131, see
+// oracle/nms.py soft_non_max_suppression_merge): `bbox_iou(boxes[i], boxes)` is elementwise, so it only broadcasts when
+// the number of kept boxes k is 1 or equals the number of candidates n.  In those two cases every kept box is replaced
+// by one weighted-mean box before the following line raises into the bare except; otherwise the plain result stands.
+int NmsWorkspace::run_merge(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float *out6_host, int cap,
+                            hipStream_t s) {
+    corner = true;
+    try {
+        launch(pred_dev, 0, 1, n_boxes, attrs, conf_thres, iou_thres, 1.f, 1.f, MAX_DET, s);
+    } catch (...) { corner = false; throw; }
+    corner = false;
+    YDS_HIP(hipStreamSynchronize(s));
+    const int n = h_counts[0], k = h_counts[1];
+    if (n > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (raise conf_thres)", n, max_cand);
+    if (n > 1 && n < 3000 && (k == n || k == 1)) {
+        std::vector<float> c((size_t)n * 6);
+        YDS_HIP(hipMemcpy(c.data(), cand.p, c.size() * sizeof(float), hipMemcpyDeviceToHost));
+        // kept order = stable descending score order over the candidates (all of them, or just the first)
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c[(size_t)a * 6 + 4] > c[(size_t)b * 6 + 4]; });
+        auto off = [&](int i, float b[4]) {
+            const float o = c[(size_t)i * 6 + 5] * 4096.f;
+            for (int d = 0; d < 4; ++d) b[d] = c[(size_t)i * 6 + d] + o;
+        };
+        double acc[4] = {0, 0, 0, 0};
+        float wsum = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float a[4], b[4];
+            off(order[k == 1 ? 0 : j], a);
+            off(j, b);
+            // bbox_iou, +1 pixel convention (model_build.py:354-381), fp32
+            float iw = fminf(a[2], b[2]) - fmaxf(a[0], b[0]) + 1.f, ih = fminf(a[3], b[3]) - fmaxf(a[1], b[1]) + 1.f;
+            iw = iw > 0.f ? iw : 0.f; ih = ih > 0.f ? ih : 0.f;
+            const float inter = iw * ih;
+            const float a1 = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f), a2 = (b[2] - b[0] + 1.f) * (b[3] - b[1] + 1.f);
+            const float iou = inter / ((a1 + a2) - inter + 1e-16f);
+            const float wgt = iou > iou_thres ? c[(size_t)j * 6 + 4] : 0.f;
+            wsum += wgt;
+            for (int d = 0; d < 4; ++d) acc[d] += (double)wgt * c[(size_t)j * 6 + d];
+        }
+        for (int r = 0; r < k; ++r)
+            for (int d = 0; d < 4; ++d) h_kept[(size_t)r * 6 + d] = (float)acc[d] / wsum;      // 0/0 -> NaN like the reference
+    }
+    const int rows = k < cap ? k : cap;
+    if (rows > 0) memcpy(out6_host, h_kept, (size_t)rows * 6 * sizeof(float));
+    return rows;
+}
+
 }  // namespace yds
 
 // ============================================================================================ C ABI
@@ -269,6 +324,24 @@ int yds_nms(yds_net *n, int image, float conf_thres, float iou_thres, int frame_
     float sy = frame_h > 0 ? (float)((double)frame_h / d->img_h) : 1.f;
     const float *pred = d->out.p + (size_t)image * d->total_boxes * d->attrs;
     *n_out = workspace().run(pred, d->total_boxes, d->attrs, conf_thres, iou_thres, sx, sy, out6_host, cap, d->stream);
+    YDS_API_END
+}
+
+int yds_detect_tiled(yds_net *n, const uint8_t *rgb_hwc_host, int h, int w, const int32_t *tiles_xyhw, int n_tiles, float conf_thres,
+                     float iou_thres, float *out6_host, int cap, int *n_out) {
+    YDS_API_BEGIN
+    yds::Darknet *d = n->d;
+    d->forward_tiles_host(rgb_hwc_host, h, w, tiles_xyhw, n_tiles);
+    *n_out = workspace().run_merge(d->tiled_pred.p, n_tiles * d->total_boxes, d->attrs, conf_thres, iou_thres, out6_host, cap, d->stream);
+    YDS_API_END
+}
+
+int yds_nms_merge_pred(const float *pred_host, int n_boxes, int attrs, float conf_thres, float iou_thres, float *out6_host, int cap, int *n_out) {
+    YDS_API_BEGIN
+    yds::DevBuf<float> pred;
+    pred.upload(pred_host, (size_t)n_boxes * attrs);
+    YDS_HIP(hipStreamSynchronize(nullptr));
+    *n_out = workspace().run_merge(pred.p, n_boxes, attrs, conf_thres, iou_thres, out6_host, cap, nullptr);
     YDS_API_END
 }
 

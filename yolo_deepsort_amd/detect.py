@@ -51,11 +51,17 @@ class ImageDetector:
     def detect(self, img):
         """img: RGB uint8 [H,W,3] -> Tensor[n,6] (x1,y1,x2,y2,conf,cls) in frame pixels, or None."""
         h, w, _ = img.shape
+        prev_time = time.time()
         if self.win_size is not None:
             win_width, win_height = self.win_size
             if not (w < win_width and h < win_height):
-                raise NotImplementedError("tiled sliding-window detection is a later row (SURVEY 8f)")
-        prev_time = time.time()
+                # img_detect.py:97-151: windows on a win_size grid, each extended by the overlap and clipped to the frame
+                overlap_x, overlap_y = int(win_width * self.overlap), int(win_height * self.overlap)
+                tiles = [(x, y, min(y + win_height + overlap_y, h) - y, min(x + win_width + overlap_x, w) - x)
+                         for x in range(0, w, win_width) for y in range(0, h, win_height)]
+                det = self.model.detect_tiled(img, tiles, self.thres, self.nms_thres)
+                logging.info("\t Inference time: %.6f s" % (time.time() - prev_time))
+                return _as_tensor(det) if det.shape[0] else None
         self.model.forward_u8(img, want_output=False)
         det = self.model.nms(0, self.thres, self.nms_thres, frame_hw=(h, w))
         logging.info("\t Inference time: %.6f s" % (time.time() - prev_time))

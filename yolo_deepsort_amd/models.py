@@ -152,6 +152,18 @@ class Darknet:
         _lib.check(_lib.load().yds_nms(self._h, image, conf_thres, iou_thres, fh, fw, _lib.ptr(out), cap, C.byref(n)))
         return out[:n.value].copy()
 
+    def detect_tiled(self, frame, tiles, conf_thres, iou_thres, cap=300):
+        """Sliding-window detection of one host frame over `tiles` = [(x, y, tile_h, tile_w), ...]
+        (ImageDetector.detect win_size branch, yolo3/detect/img_detect.py:97-151) -> [n,6] in frame pixels."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w, _ = frame.shape
+        rects = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, 4)
+        out = np.empty((cap, 6), np.float32)
+        n = C.c_int(0)
+        _lib.check(_lib.load().yds_detect_tiled(self._h, _lib.ptr(frame), h, w, _lib.ptr(rects), rects.shape[0], conf_thres, iou_thres,
+                                                _lib.ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
     def layer_shape(self, i):
         c, h, w = C.c_int(), C.c_int(), C.c_int()
         _lib.check(_lib.load().yds_darknet_layer_shape(self._h, i, C.byref(c), C.byref(h), C.byref(w)))
