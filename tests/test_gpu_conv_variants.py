@@ -1,0 +1,120 @@
+"""Every implicit-GEMM conv kernel variant (through the C ABI entry yds_conv_run) vs a float64 numpy convolution.
+
+The detector tests only exercise the variant the autotuner picks per layer; this file pins each tile shape / staging
+scheme on its own: 3x3 s1, 3x3 s2, 1x1, ragged M and Cout edges, every activation, both residual modes.
+Tolerance: 1e-3 of the output scale (north_star) - the kernels sit at ~1e-6."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+ACT = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3}
+
+
+def _act(v, act):
+    if act == 1:
+        return np.where(v > 0, v, v * 0.1)
+    if act == 2:
+        sp = np.where(v > 20, v, np.log1p(np.exp(np.minimum(v, 20))))
+        return v * np.tanh(sp)
+    if act == 3:
+        return np.maximum(v, 0)
+    return v
+
+
+def _conv_ref(x, w, bias, k, s, act, res, res_mode):
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (wd + 2 * pad - k) // s + 1
+    xp = np.zeros((n, h + 2 * pad, wd + 2 * pad, cin), np.float64)
+    xp[:, pad:pad + h, pad:pad + wd] = x
+    y = np.zeros((n, ho, wo, cout), np.float64)
+    w64 = w.astype(np.float64).reshape(cout, k, k, cin)
+    for kh in range(k):
+        for kw in range(k):
+            patch = xp[:, kh:kh + s * ho:s, kw:kw + s * wo:s]
+            y += patch @ w64[:, kh, kw].T
+    y += bias.astype(np.float64)
+    if res_mode == 2:
+        y += res
+    y = _act(y, act)
+    if res_mode == 1:
+        y += res
+    return y.transpose(0, 3, 1, 2)
+
+
+def _run(L, variant, x, w, bias, k, s, act, res, res_mode):
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // s + 1, (wd + 2 * pad - k) // s + 1
+    y = np.empty((n, cout, ho, wo), F32)
+    L.check(L.load().yds_conv_run(variant, n, h, wd, cin, cout, k, s, act, res_mode, L.ptr(x), L.ptr(w), L.ptr(bias),
+                                  L.ptr(res) if res is not None else None, L.ptr(y)))
+    return y
+
+
+CASES = [  # n, h, w, cin, cout, k, s, act, res_mode
+    (2, 19, 19, 64, 128, 3, 1, "leaky", 0),
+    (1, 38, 38, 128, 256, 3, 1, "leaky", 1),          # fused shortcut
+    (3, 20, 12, 96, 160, 3, 2, "mish", 0),            # stride 2, ragged M / Cout tiles
+    (2, 26, 26, 256, 255, 1, 1, "linear", 0),         # head: fp32 output, Cout % 4 != 0
+    (1, 16, 8, 64, 64, 3, 1, "relu", 2),              # ReID basic block (residual before the activation)
+    (5, 13, 13, 32, 512, 1, 1, "leaky", 0),
+    (1, 40, 40, 32, 64, 3, 1, "mish", 1),
+]
+
+
+@pytest.mark.parametrize("math", [1, 0])
+def test_every_conv_variant_vs_float64(math):
+    from yolo_deepsort_amd import _lib as L
+    L.init(0)
+    lib = L.load()
+    lib.yds_conv_variant_name.restype = C.c_char_p
+    prev = lib.yds_get_conv_math()
+    L.check(lib.yds_set_conv_math(math))
+    try:
+        nvar = lib.yds_conv_num_variants()
+        names = [lib.yds_conv_variant_name(v).decode() for v in range(nvar)]
+        mine = [v for v, nme in enumerate(names) if ("f16x3" in nme) == bool(math) and "direct" not in nme]
+        assert len(mine) >= 4
+        rng = np.random.RandomState(17)
+        worst = {}
+        for n, h, wd, cin, cout, k, s, act, res_mode in CASES:
+            x = rng.standard_normal((n, h, wd, cin)).astype(F32)
+            w = (rng.standard_normal((cout, k * k * cin)) / np.sqrt(k * k * cin)).astype(F32)
+            bias = rng.standard_normal(cout).astype(F32)
+            pad = (k - 1) // 2
+            ho, wo = (h + 2 * pad - k) // s + 1, (wd + 2 * pad - k) // s + 1
+            res = rng.standard_normal((n, ho, wo, cout)).astype(F32) if res_mode else None
+            want = _conv_ref(x, w, bias, k, s, ACT[act], res, res_mode)
+            scale = float(np.abs(want).max())
+            for v in mine:
+                got = _run(L, v, x, w, bias, k, s, ACT[act], res, res_mode)
+                err = float(np.abs(got - want).max()) / scale
+                worst[names[v]] = max(worst.get(names[v], 0.0), err)
+                assert err < 1e-3, (names[v], (n, h, wd, cin, cout, k, s, act, res_mode), err)
+        print({k: f"{v:.1e}" for k, v in worst.items()})
+    finally:
+        lib.yds_set_conv_math(prev)
+
+
+def test_direct_rgb_kernel_vs_float64():
+    from yolo_deepsort_amd import _lib as L
+    L.init(0)
+    lib = L.load()
+    lib.yds_conv_variant_name.restype = C.c_char_p
+    direct = [v for v in range(lib.yds_conv_num_variants()) if b"direct" in lib.yds_conv_variant_name(v)]
+    assert len(direct) == 1
+    rng = np.random.RandomState(3)
+    for cout, act in ((32, "leaky"), (64, "relu"), (32, "mish")):
+        x = np.zeros((2, 33, 47, 4), F32)
+        x[..., :3] = rng.uniform(0, 1, (2, 33, 47, 3))
+        w = (rng.standard_normal((cout, 9 * 4)) / 5).astype(F32)
+        bias = rng.standard_normal(cout).astype(F32)
+        want = _conv_ref(x, w, bias, 3, 1, ACT[act], None, 0)
+        got = _run(L, direct[0], x, w, bias, 3, 1, ACT[act], None, 0)
+        assert float(np.abs(got - want).max()) / float(np.abs(want).max()) < 1e-5

@@ -1,0 +1,88 @@
+// Matrix-pipe probe (tuning aid): v_mfma_f32_32x32x16_f16 issue rate alone, with the f16x3 kernel's LDS fragment
+// reads, and with its per-K-step barrier.  Reports TFLOP/s of MFMA work (dense fp16 peak = 2500 at 2.4 GHz).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int ROWB = 144;
+
+// MODE 0: MFMA only (8 independent accumulators, 24 MFMAs per step)
+// MODE 1: + 16 ds_read_b128 per step (fragments re-read every step)
+// MODE 2: + s_barrier per step
+// MODE 3: MODE 2 with fragment reads of step k+1 issued before the MFMAs of step k (software pipelining)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void probe(float *out, int steps) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * 256 * ROWB / 4; i += 256) reinterpret_cast<float *>(lds)[i] = 0.001f * (i & 15);
+    __syncthreads();
+    f32x16 acc1[2][2], acc2[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0; acc2[i][j][e] = 0; }
+    const int frag = (lane & 31) * ROWB + (lane >> 5) * 16;
+    const char *a_lds = lds + (wave >> 1) * 64 * ROWB + frag, *b_lds = lds + 128 * ROWB + (wave & 1) * 64 * ROWB + frag;
+    h8 ah[2][2], al[2][2], bh[2][2], bl[2][2];       // [substep][tile]
+    auto read = [&](int s, int buf) {
+        const char *a = a_lds + buf * 256 * ROWB, *b = b_lds + buf * 256 * ROWB;
+        for (int i = 0; i < 2; ++i) {
+            ah[s][i] = *reinterpret_cast<const h8 *>(a + i * 32 * ROWB + s * 32);
+            al[s][i] = *reinterpret_cast<const h8 *>(a + i * 32 * ROWB + s * 32 + 64);
+            bh[s][i] = *reinterpret_cast<const h8 *>(b + i * 32 * ROWB + s * 32);
+            bl[s][i] = *reinterpret_cast<const h8 *>(b + i * 32 * ROWB + s * 32 + 64);
+        }
+    };
+    auto mma = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bh[s][j], acc1[i][j], 0, 0, 0);
+                acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s][i], bl[s][j], acc2[i][j], 0, 0, 0);
+                acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s][i], bh[s][j], acc2[i][j], 0, 0, 0);
+            }
+    };
+    read(0, 0); read(1, 0);
+    for (int k = 0; k < steps; ++k) {
+        if (MODE == 0) { mma(0); mma(1); }
+        if (MODE == 1 || MODE == 2) { read(0, k & 1); read(1, k & 1); mma(0); mma(1); if (MODE == 2) __syncthreads(); }
+        if (MODE == 3) {
+            mma(0);                 // fragments of substep 0 were read during the previous step
+            __builtin_amdgcn_sched_barrier(0);
+            read(0, (k + 1) & 1);   // next step's substep-0 fragments fly under substep 1's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            read(1, (k + 1) & 1);
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) s += acc1[i][j][e] + acc2[i][j][e];
+    if (s == 123.456f) out[0] = s;
+}
+
+template <int MODE> void run(const char *name, int wg_per_cu) {
+    float *o; hipMalloc(&o, 4);
+    const int steps = 2000, grid = 256 * wg_per_cu;
+    size_t smem = 2 * 256 * ROWB;
+    hipFuncSetAttribute(reinterpret_cast<const void *>(probe<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int r = 0; r < 4; ++r) {
+        hipEventRecord(e0);
+        probe<MODE><<<grid, 256, smem>>>(o, steps);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    double flops = (double)grid * 4 * steps * 24 * 32768.0;
+    printf("%-44s %d WG/CU: %8.1f us  %7.1f TFLOP/s MFMA  (%.1f fp32-equivalent)\n", name, wg_per_cu, best * 1e3, flops / best / 1e9, flops / best / 1e9 / 3);
+    hipFree(o);
+}
+int main() {
+    for (int w : {1, 2}) {
+        run<0>("mfma only", w);
+        run<1>("mfma + 16 ds_read_b128 / step", w);
+        run<2>("mfma + ds_read + barrier", w);
+        run<3>("software-pipelined reads + barrier", w);
+    }
+    return 0;
+}

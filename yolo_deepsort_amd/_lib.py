@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libydsort.so")
+_TAG = os.environ.get("YDS_BUILD_TAG", "")          # experiment builds (see build.py)
+LIB_PATH = os.path.join(HERE, "libydsort" + ("_" + _TAG if _TAG else "") + ".so")
 
 
 class YdsError(RuntimeError):
@@ -57,6 +58,7 @@ SIGNATURES = {
     "yds_set_conv_math": (_I, [_I]),
     "yds_get_conv_math": (_I, []),
     "yds_conv_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "yds_conv_run": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "yds_nms": (_I, [_P, _I, _F, _F, _I, _I, _P, _I, _P]),
     "yds_nms_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),
     "yds_nms_merge_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),

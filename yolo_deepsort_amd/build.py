@@ -7,11 +7,13 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "build")
-LIB = os.path.join(HERE, "libydsort.so")
+# YDS_BUILD_TAG / YDS_EXTRA_FLAGS: experiment builds (tools/) next to the product library, e.g. ablation -D switches
+TAG = os.environ.get("YDS_BUILD_TAG", "")
+OBJ = os.path.join(HERE, "build" + ("_" + TAG if TAG else ""))
+LIB = os.path.join(HERE, "libydsort" + ("_" + TAG if TAG else "") + ".so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC,
-         "-Wno-unused-result", "-ffp-contract=off"]
+         "-Wno-unused-result", "-ffp-contract=off"] + os.environ.get("YDS_EXTRA_FLAGS", "").split()
 
 
 def _newer(target, deps):

@@ -75,11 +75,11 @@ inline int plan_tile_map(ConvKernelArgs &k, int BM, int BN) {
 // and row contiguous: bias, residual and output move as float4 along the channel axis.  One pass per row of waves
 // keeps the staging area at (BM/WM) x (BN+4) floats, which fits inside every variant's main-loop allocation.
 // ACT / RES are compile-time.
-template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256>
 __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
     constexpr int ROWS = BM / WM, LD = BN + 4, C4 = BN / 4;        // staged rows, padded row length, float4 per row
-    constexpr int RSTEP = 256 / C4;                                  // rows covered by one sweep of the 256 threads
-    static_assert(256 % C4 == 0, "tile width must divide the workgroup");
+    constexpr int RSTEP = NT / C4;                                   // rows covered by one sweep of the NT threads
+    static_assert(NT % C4 == 0, "tile width must divide the workgroup");
     const int lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
     const int col = lane & 31, rsel = (lane >> 5) * 4;
     const int c4 = tid % C4, rr = tid / C4;

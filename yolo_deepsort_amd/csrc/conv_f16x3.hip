@@ -26,6 +26,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWB = 144;                 // bytes per LDS row
+#ifndef YDS_F16_ABL
+#define YDS_F16_ABL 0                     // tools/ ablation builds: 1 no global loads in the K loop, 2 + no LDS stores, 3 no MFMA
+#endif
 constexpr float A_SCALE = 1.f / 256.f, LO_SCALE = 2048.f;
 
 __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
-    const int nk = p.Kpad / 32;
+    const int nk = YDS_F16_ABL == 4 ? 1 : p.Kpad / 32;       // ablation 4: prologue + epilogue only
     load_tiles();
     store_tiles(0);
     if (STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(STAGGER / 4);
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more) { advance_k(); load_tiles(); }
+        if (more) { advance_k(); if (YDS_F16_ABL != 1 && YDS_F16_ABL != 2) load_tiles(); }
         const char *a = a_lds + cur * BM * ROWB, *b = b_lds + cur * BN * ROWB;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                      // two MFMA k-steps of 16 per staged tile of 32
@@ -198,12 +201,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+                    if (YDS_F16_ABL == 3) { acc1[i][j][0] += (float)ah[i][0] + (float)bl[j][0] + (float)al[i][0] + (float)bh[j][0]; continue; }
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
                     acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
                     acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
                 }
         }
-        if (more) store_tiles(cur ^ 1);
+        if (more && YDS_F16_ABL != 2) store_tiles(cur ^ 1);
         __syncthreads();
     }
     // recombine the two accumulator sets and undo the activation scale
@@ -214,34 +218,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     static_assert((BM / WM) * (BN + 4) * 4 <= 2 * (BM + BN) * ROWB, "epilogue staging must fit the main-loop LDS");
+    if (YDS_F16_ABL == 5) {                                   // ablation 5: K loop only
+        float t = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int e = 0; e < 16; ++e) t += acc1[i][j][e];
+        if (t == 123.456f) p.y[0] = t;
+        return;
+    }
     conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc1, reinterpret_cast<float *>(smem16), m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for pre-split (H16) inputs: both operands are opaque 16-byte chunks, so they go global -> LDS with
-// global_load_lds_dwordx4 (no staging VGPRs, no ds_write, no conversion) through an NS-deep ring of K=16 stages.
-// The staged kernel above keeps exactly one tile of loads in flight per workgroup and its K loop runs at the
-// latency of that batch; here NS-1 stages are in flight and the wave only waits (counted vmcnt) for the oldest.
-//   stage  = BM + BN rows of 64 B: [16 hi | 16 lo] fp16 = one MFMA k-step; row r keeps chunk c at position
-//            c ^ ((r >> 2) & 3) (the DMA writes lane-linear, so the swizzle is applied to the SOURCE address and
-//            again by the fragment reads; 16 consecutive rows then hit 16 distinct 16-byte bank slots)
+// global_load_lds_dwordx4 (no staging VGPRs, no ds_write, no conversion) through an NS-deep ring of K=32 stages.
+//   stage  = BM + BN rows of 128 B = one whole [32 hi | 32 lo] group per row (a full cache line per pixel / filter
+//            row, 8 rows per wave instruction); row r keeps its 16-byte chunk c at position c ^ ((r >> 1) & 7): the
+//            DMA writes lane-linear, so the swizzle is applied to the SOURCE address and again by the fragment reads
+//            (a ds_read_b128 lane group then hits 16 distinct 16-byte bank slots)
 //   ring   : iteration t waits for tile t (vmcnt = DMAs of the younger tiles), one s_barrier, re-fills the stage
-//            that iteration t-1 finished reading, then 12 MFMAs per wave on stage t % NS
-//   zero padding: out-of-image taps fetch from a 16-byte zero page instead of branching.
+//            that iteration t-1 finished reading, then 24 MFMAs per wave on stage t % NS
+//   zero padding: out-of-image taps fetch from a zero page instead of branching
+//   WM x WN waves of 64 threads, each owning a 64x64 (TM = TN = 2) or smaller sub-tile.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NS, int ACT, int RES>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_dma(ConvKernelArgs p, const void *zero_page) {
-    constexpr int WM = 2, WN = 2;
+constexpr int ZERO_PAGE_BYTES = 64 * 1024;                      // >= Cin * 4 + 128 for every layer (checked at launch)
+
+template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES>
+__global__ __launch_bounds__(WM * WN * 64, (NS * (BM + BN) * 128 <= 80 * 1024 && WM * WN == 4) ? 2 : 1)
+void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
+    constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int ROW = 64;
+    constexpr int ROW = 128;
     constexpr int A_BYTES = BM * ROW, STAGE = (BM + BN) * ROW;
-    constexpr int A_INST = BM / 64, B_INST = BN / 64;          // DMA instructions per wave per stage (16 rows each)
+    constexpr int A_INST = BM / (8 * NW), B_INST = BN / (8 * NW);   // DMA instructions per wave per stage (8 rows each)
     constexpr int IN = A_INST + B_INST;
-    static_assert(NS >= 3 && NS <= 6, "ring depth");
+    static_assert(NS >= 2 && NS <= 4 && A_INST >= 1 && B_INST >= 1, "ring shape");
     extern __shared__ __attribute__((aligned(16))) char ring[];     // [NS][STAGE]
 
     const int tid = threadIdx.x;
@@ -254,14 +267,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_dma(ConvKernelArgs p,
         m0 = tm * BM;
         n0 = tn * BN;
     }
-    // DMA lane roles: instruction q of this wave fills rows (q*4 + wave)*16 .. +15; lane -> (row, position)
-    const int drow = lane >> 2, dpos = lane & 3;
-    int a_base[A_INST], a_iy[A_INST], a_ix[A_INST], a_sc[A_INST];
+    // DMA lane roles: instruction q of this wave fills rows (q*NW + wave)*8 .. +7; lane -> (row, 16-byte position)
+    const int drow = lane >> 3, dpos = lane & 7;
+    int a_base[A_INST], a_iy[A_INST], a_ix[A_INST];
+    const char *a_src[A_INST];                                  // this tap: group-0 address of the lane's chunk, or the zero page
     const int HoWo = p.Ho * p.Wo;
 #pragma unroll
     for (int q = 0; q < A_INST; ++q) {
-        const int row = (q * 4 + wave) * 16 + drow;
-        a_sc[q] = dpos ^ ((row >> 2) & 3);                      // logical chunk this lane fetches
+        const int row = (q * NW + wave) * 8 + drow;
         const int m = m0 + row;
         if (m < p.M) {
             int img = m / HoWo, rem = m - img * HoWo;
@@ -275,38 +288,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_dma(ConvKernelArgs p,
             a_base[q] = 0;
         }
     }
-    const char *w_row[B_INST];
-    int b_sc[B_INST];
+    // logical chunk fetched by this lane: position dpos of row r holds chunk dpos ^ ((r >> 1) & 7); r % 8 == drow for
+    // every instruction (row bases are multiples of 8) and bit 3 of r is bit 0 of (q*NW + wave)
+    auto src_chunk = [&](int q) { return (dpos ^ ((((q * NW + wave) * 8 + drow) >> 1) & 7)) * 16; };
+    const char *w_src[B_INST];
 #pragma unroll
     for (int q = 0; q < B_INST; ++q) {
-        const int row = (q * 4 + wave) * 16 + drow;
-        b_sc[q] = dpos ^ ((row >> 2) & 3);
-        w_row[q] = reinterpret_cast<const char *>(p.w) + (size_t)min(n0 + row, p.Cout - 1) * p.Kpad * 4;
+        const int row = (q * NW + wave) * 8 + drow;
+        w_src[q] = reinterpret_cast<const char *>(p.w) + (size_t)min(n0 + row, p.Cout - 1) * p.Kpad * 4 + src_chunk(q);
     }
-    // byte offset of logical chunk sc (0,1: hi k0-7 / k8-15; 2,3: lo) of half h inside a 128-byte group
-    auto chunk_off = [](int h, int sc) { return (sc < 2 ? 0 : 64) + (2 * h + (sc & 1)) * 16; };
-
-    int kt_issue = 0, kh = 0, kw = 0, kc = 0;                   // next K16 tile to issue and its (tap, channel) position
-    auto issue = [&](int stage) {
-        const int h = (kc >> 4) & 1, gb = kc & ~31;
-        char *sa = ring + stage * STAGE, *sb = sa + A_BYTES;
-        const int tap_off = (kh * p.W + kw) * p.ldx + gb;
+    int kh = 0, kw = 0, kc = 0;                                 // (tap, channel group) of the next tile to issue
+    auto set_tap = [&]() {
 #pragma unroll
         for (int q = 0; q < A_INST; ++q) {
             int iy = a_iy[q] + kh, ix = a_ix[q] + kw;
             bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const char *src = ok ? reinterpret_cast<const char *>(p.x + (a_base[q] + tap_off)) + chunk_off(h, a_sc[q])
-                                 : reinterpret_cast<const char *>(zero_page);
-            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(sa + (q * 4 + wave) * 16 * ROW), 16, 0, 0);
+            a_src[q] = ok ? reinterpret_cast<const char *>(p.x + (a_base[q] + (kh * p.W + kw) * p.ldx)) + src_chunk(q) : zero_page;
         }
+    };
+    set_tap();
+    auto issue = [&](int stage) {
+        char *sa = ring + stage * STAGE, *sb = sa + A_BYTES;
+        const int kb = kc * 4;                                  // uniform byte offset of this channel group
+#pragma unroll
+        for (int q = 0; q < A_INST; ++q)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[q] + kb), (lds_void_t *)(sa + (q * NW + wave) * 8 * ROW), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < B_INST; ++q) {
-            const char *src = w_row[q] + (size_t)(kt_issue >> 1) * 128 + chunk_off(kt_issue & 1, b_sc[q]);
-            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(sb + (q * 4 + wave) * 16 * ROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)w_src[q], (lds_void_t *)(sb + (q * NW + wave) * 8 * ROW), 16, 0, 0);
+            w_src[q] += 128;
         }
-        ++kt_issue;
-        kc += 16;
-        if (kc >= p.Cin) { kc = 0; if (++kw == p.ksize) { kw = 0; ++kh; } }
+        kc += 32;
+        if (kc >= p.Cin) { kc = 0; if (++kw == p.ksize) { kw = 0; ++kh; } set_tap(); }
     };
 
     f32x16 acc1[TM][TN], acc2[TM][TN];
@@ -317,15 +330,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_dma(ConvKernelArgs p,
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
-    const int nk = p.K / 16;                                    // Cin % 32 == 0 on this path
+    const int nk = p.K / 32;                                    // Cin % 32 == 0 on this path
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s);
+    if (STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(STAGGER / 4);
 
-    // fragment addressing: row = lane & 31 (+ tile offsets, multiples of 32), chunk kb / 2+kb at swizzled position
-    const int swz = (lane >> 2) & 3, kb = lane >> 5;
+    // fragment addressing: row = lane & 31 (+ tile offsets, multiples of 32); chunk ids inside a row: hi k 0-7 / 8-15 /
+    // 16-23 / 24-31 = 0..3, lo = 4..7; k-substep s, lane half kb -> chunks 2s+kb (hi) and 4+2s+kb (lo)
+    const int swz = (lane >> 1) & 7, kb = lane >> 5;
     const int a_frag = (wm * (BM / WM) + (lane & 31)) * ROW, b_frag = A_BYTES + (wn * (BN / WN) + (lane & 31)) * ROW;
-    const int pos_hi = (kb ^ swz) * 16, pos_lo = ((2 + kb) ^ swz) * 16;
+    int pos_hi[2], pos_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { pos_hi[s] = ((2 * s + kb) ^ swz) * 16; pos_lo[s] = ((4 + 2 * s + kb) ^ swz) * 16; }
 
     for (int t = 0; t < nk; ++t) {
         // tile t must have landed; the NS-2 younger tiles may stay in flight
@@ -333,32 +350,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_dma(ConvKernelArgs p,
         switch (younger) {
             case 0: wait_vmcnt<0>(); break;
             case 1: wait_vmcnt<IN>(); break;
-            case 2: wait_vmcnt<2 * IN>(); break;
-            case 3: wait_vmcnt<3 * IN>(); break;
-            default: wait_vmcnt<4 * IN>(); break;
+            default: wait_vmcnt<2 * IN>(); break;
         }
         __builtin_amdgcn_s_barrier();
         if (t + NS - 1 < nk) issue((t + NS - 1) % NS);
         const char *st = ring + (t % NS) * STAGE;
-        h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ah[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_hi);
-            al[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_lo);
-        }
+        for (int s = 0; s < 2; ++s) {
+            h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            bh[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_hi);
-            bl[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_lo);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_hi[s]);
+                al[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_lo[s]);
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
-                acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
-                acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
+                bh[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_hi[s]);
+                bl[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_lo[s]);
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
+                }
+        }
     }
     __syncthreads();                                            // every wave is done with the ring
 #pragma unroll
@@ -368,34 +386,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3_dma(ConvKernelArgs p,
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     static_assert((BM / WM) * (BN + 4) * 4 <= NS * STAGE, "epilogue staging must fit the ring");
-    conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc1, reinterpret_cast<float *>(ring), m0, n0, tid);
+    conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT>(p, acc1, reinterpret_cast<float *>(ring), m0, n0, tid);
 }
 
-static const void *zero_page_dev() {
+static const char *zero_page_dev() {
     static void *z = nullptr;
     if (!z) {
-        YDS_HIP(hipMalloc(&z, 256));
-        YDS_HIP(hipMemset(z, 0, 256));
+        YDS_HIP(hipMalloc(&z, ZERO_PAGE_BYTES));
+        YDS_HIP(hipMemset(z, 0, ZERO_PAGE_BYTES));
     }
-    return z;
+    return static_cast<const char *>(z);
 }
 
-template <int BM, int BN, int NS, int ACT, int RES> static void launch_inst_dma(ConvKernelArgs k, hipStream_t s) {
-    constexpr size_t smem = (size_t)NS * (BM + BN) * 64;
+template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES> static void launch_inst_dma(ConvKernelArgs k, hipStream_t s) {
+    constexpr size_t smem = (size_t)NS * (BM + BN) * 128;
     static bool attr_set = false;
-    auto kern = conv_igemm_f16x3_dma<BM, BN, NS, ACT, RES>;
+    auto kern = conv_igemm_f16x3_dma<BM, BN, WM, WN, NS, ACT, RES>;
     if (!attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid(plan_tile_map(k, BM, BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, k, zero_page_dev());
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, k, zero_page_dev());
     YDS_HIP(hipGetLastError());
 }
 
-template <int BM, int BN, int NS> static void launch_cfg_dma(const ConvKernelArgs &k, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int NS> static void launch_cfg_dma(const ConvKernelArgs &k, hipStream_t s) {
     if (k.fmt_x != FMT_H16 || k.Cin % 32) fail("conv: the LDS-DMA kernel needs a pre-split (H16) input");
-#define YDS_CALL(A, R) launch_inst_dma<BM, BN, NS, A, R>(k, s)
+    if ((size_t)k.Cin * 4 + 128 > (size_t)ZERO_PAGE_BYTES) fail("conv: %d input channels exceed the zero page of the LDS-DMA kernel", k.Cin);
+#define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R>(k, s)
     YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
 }
@@ -427,8 +446,8 @@ template <int BM, int BN> static void launch_cfg16(const ConvKernelArgs &k, hipS
 
 const char *conv_f16x3_variant_name(int v) {
     static const char *names[kF16Variants] = {"conv_igemm_f16x3<128,128>", "conv_igemm_f16x3<64,128>", "conv_igemm_f16x3<128,64>",
-                                              "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,5>", "conv_igemm_f16x3_dma<128,128,4>",
-                                              "conv_igemm_f16x3_dma<64,128,5>", "conv_igemm_f16x3_dma<64,64,6>"};
+                                              "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,2x2,2>", "conv_igemm_f16x3_dma<256,128,4x2,3>",
+                                              "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
 }
 
@@ -438,10 +457,10 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s) {
         case 1: launch_cfg16<64, 128>(k, s); break;
         case 2: launch_cfg16<128, 64>(k, s); break;
         case 3: launch_cfg16<64, 64>(k, s); break;
-        case 4: launch_cfg_dma<128, 128, 5>(k, s); break;
-        case 5: launch_cfg_dma<128, 128, 4>(k, s); break;
-        case 6: launch_cfg_dma<64, 128, 5>(k, s); break;
-        default: launch_cfg_dma<64, 64, 6>(k, s); break;
+        case 4: launch_cfg_dma<128, 128, 2, 2, 2>(k, s); break;
+        case 5: launch_cfg_dma<256, 128, 4, 2, 3>(k, s); break;
+        case 6: launch_cfg_dma<128, 256, 2, 4, 3>(k, s); break;
+        default: launch_cfg_dma<128, 128, 2, 2, 3>(k, s); break;
     }
 }
 

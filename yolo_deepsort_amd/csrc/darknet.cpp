@@ -686,6 +686,44 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
     YDS_API_END
 }
+int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int res_mode, const float *x_nhwc,
+                 const float *w_okkc, const float *bias, const float *res_nhwc, float *y_nchw) {
+    YDS_API_BEGIN
+    using namespace yds;
+    const int pad = (ksize - 1) / 2, ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    const int K = ksize * ksize * cin, kpad = (K + 31) / 32 * 32, ldy = (cout + 3) / 4 * 4;
+    if (cin % 4) fail("conv_run: input channels must be a multiple of 4");
+    std::vector<float> hw((size_t)cout * kpad, 0.f);
+    for (int o = 0; o < cout; ++o) memcpy(&hw[(size_t)o * kpad], w_okkc + (size_t)o * K, (size_t)K * sizeof(float));
+    const size_t npix_in = (size_t)n * h * w, npix_out = (size_t)n * ho * wo;
+    DevBuf<float> x, raw, wt, b, y(npix_out * ldy), r, rraw, out(npix_out * cout);
+    DevBuf<uint16_t> wt16;
+    wt.upload(hw.data(), hw.size()); b.upload(bias, cout);
+    std::vector<uint16_t> split;
+    pack_weights_f16x3(hw.data(), cout, kpad, split);
+    wt16.upload(split.data(), split.size());
+    const bool f16 = conv_math() == MATH_F16X3;
+    ConvArgs a;
+    a.x = View{nullptr, n, h, w, cin, cin, (f16 && cin % 32 == 0) ? FMT_H16 : FMT_F32};
+    a.y = View{y.p, n, ho, wo, cout, ldy, (f16 && cout % 32 == 0) ? FMT_H16 : FMT_F32};
+    raw.upload(x_nhwc, npix_in * cin);
+    if (a.x.fmt == FMT_H16) { x.alloc(npix_in * cin); a.x.p = x.p; launch_pack_h16(raw.p, a.x, nullptr); }
+    else a.x.p = raw.p;
+    a.w = wt.p; a.w16 = wt16.p; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
+    if (res_mode) {
+        if (!res_nhwc) fail("conv_run: residual mode %d without a residual tensor", res_mode);
+        a.res = View{nullptr, n, ho, wo, cout, cout, a.y.fmt};
+        rraw.upload(res_nhwc, npix_out * cout);
+        if (a.res.fmt == FMT_H16) { r.alloc(npix_out * cout); a.res.p = r.p; launch_pack_h16(rraw.p, a.res, nullptr); }
+        else a.res.p = rraw.p;
+        a.res_mode = res_mode;
+    }
+    YDS_HIP(hipDeviceSynchronize());
+    launch_conv(a, nullptr, variant);
+    launch_nhwc_to_nchw(a.y, out.p, nullptr);
+    YDS_HIP(hipMemcpy(y_nchw, out.p, npix_out * cout * sizeof(float), hipMemcpyDeviceToHost));
+    YDS_API_END
+}
 int yds_darknet_load_injection_sets(yds_net *n, const float *rows_host, const int32_t *offsets_host, int n_sets, float logit) {
     YDS_API_BEGIN
     n->d->load_injection_sets(rows_host, offsets_host, n_sets, logit);
