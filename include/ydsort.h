@@ -191,6 +191,8 @@ const char *yds_conv_variant_name(int variant);
  * average launch duration in us and the tile variant that was picked. */
 int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual,
                    int iters, double *avg_us, int *variant);
+/* tuning aid (YDS_TIMING experiment builds only): accumulated s_memtime phase counters of the LDS-DMA conv kernel */
+int yds_debug_prof(uint64_t *out8, int reset);
 /* parity-test entry: one convolution through a chosen kernel variant (formats as the planner would pick them for the
  * current conv math).  x NHWC [n,h,w,cin], w [cout][kh][kw][cin] (BN already folded), res NHWC or NULL
  * (res_mode 0 none, 1 after the activation, 2 before it), y NCHW [n,cout,ho,wo]. */

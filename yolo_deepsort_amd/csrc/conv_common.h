@@ -155,5 +155,6 @@ void launch_conv_direct(const ConvKernelArgs &k, hipStream_t s);
 constexpr int kF16Variants = 8;            // 0-3 register-staged tiles, 4-7 LDS-DMA ring (pre-split inputs only)
 const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
+void conv_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING builds: wait / barrier / body / total cycles, steps, waves
 
 }  // namespace yds

@@ -26,6 +26,21 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWB = 144;                 // bytes per LDS row
+#ifndef YDS_PRIO_MODE
+#define YDS_PRIO_MODE 0                   // experiment: static wave priorities to keep co-resident workgroups out of lock-step
+#endif
+__device__ __forceinline__ void set_static_prio() {
+    if (YDS_PRIO_MODE == 1) {             // by hardware wave slot (HW_ID[3:0]): the two waves sharing a SIMD differ
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        if (slot & 1) __builtin_amdgcn_s_setprio(3);
+    } else if (YDS_PRIO_MODE == 2) {      // by dispatch wave of 256 workgroups
+        if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(3);
+    }
+}
+#ifndef YDS_TIMING
+#define YDS_TIMING 0                      // experiment: s_memtime phase accounting in the LDS-DMA kernel (yds_debug_prof)
+#endif
+__device__ unsigned long long yds_prof[8];
 #ifndef YDS_F16_ABL
 #define YDS_F16_ABL 0                     // tools/ ablation builds: 1 no global loads in the K loop, 2 + no LDS stores, 3 no MFMA
 #endif
@@ -62,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
         m0 = tm * BM;
         n0 = tn * BN;
     }
+    set_static_prio();
     const int cq = tid & 7;          // which 4 of the 32 k (A, fp32) / which 16-byte chunk of the 128-byte weight row
     const int r0 = tid >> 3;         // first staged row; further rows at +32
 
@@ -267,6 +283,7 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         m0 = tm * BM;
         n0 = tn * BN;
     }
+    set_static_prio();
     // DMA lane roles: instruction q of this wave fills rows (q*NW + wave)*8 .. +7; lane -> (row, 16-byte position)
     const int drow = lane >> 3, dpos = lane & 7;
     int a_base[A_INST], a_iy[A_INST], a_ix[A_INST];
@@ -307,17 +324,18 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         }
     };
     set_tap();
-    auto issue = [&](int stage) {
+    // one DMA instruction of the tile being issued: pieces 0..A_INST-1 fetch activation rows, the rest filter rows
+    auto piece = [&](int stage, int q) {
         char *sa = ring + stage * STAGE, *sb = sa + A_BYTES;
-        const int kb = kc * 4;                                  // uniform byte offset of this channel group
-#pragma unroll
-        for (int q = 0; q < A_INST; ++q)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[q] + kb), (lds_void_t *)(sa + (q * NW + wave) * 8 * ROW), 16, 0, 0);
-#pragma unroll
-        for (int q = 0; q < B_INST; ++q) {
-            __builtin_amdgcn_global_load_lds((glb_void_t *)w_src[q], (lds_void_t *)(sb + (q * NW + wave) * 8 * ROW), 16, 0, 0);
-            w_src[q] += 128;
+        if (q < A_INST) {
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[q] + kc * 4), (lds_void_t *)(sa + (q * NW + wave) * 8 * ROW), 16, 0, 0);
+        } else {
+            const int b = q - A_INST;
+            __builtin_amdgcn_global_load_lds((glb_void_t *)w_src[b], (lds_void_t *)(sb + (b * NW + wave) * 8 * ROW), 16, 0, 0);
+            w_src[b] += 128;
         }
+    };
+    auto advance_tile = [&]() {
         kc += 32;
         if (kc >= p.Cin) { kc = 0; if (++kw == p.ksize) { kw = 0; ++kh; } set_tap(); }
     };
@@ -333,7 +351,11 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     const int nk = p.K / 32;                                    // Cin % 32 == 0 on this path
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) issue(s);
+        if (s < nk) {
+#pragma unroll
+            for (int q = 0; q < IN; ++q) piece(s, q);
+            advance_tile();
+        }
     if (STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(STAGGER / 4);
 
     // fragment addressing: row = lane & 31 (+ tile offsets, multiples of 32); chunk ids inside a row: hi k 0-7 / 8-15 /
@@ -344,39 +366,85 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) { pos_hi[s] = ((2 * s + kb) ^ swz) * 16; pos_lo[s] = ((4 + 2 * s + kb) ^ swz) * 16; }
 
-    for (int t = 0; t < nk; ++t) {
-        // tile t must have landed; the NS-2 younger tiles may stay in flight
-        const int younger = min(NS - 2, nk - 1 - t);
-        switch (younger) {
-            case 0: wait_vmcnt<0>(); break;
-            case 1: wait_vmcnt<IN>(); break;
-            default: wait_vmcnt<2 * IN>(); break;
-        }
-        __builtin_amdgcn_s_barrier();
-        if (t + NS - 1 < nk) issue((t + NS - 1) % NS);
+    // The wave issues in order, so memory instructions are placed BETWEEN the MFMAs of a k-substep (each MFMA keeps the
+    // matrix pipe busy for 32 cycles, which pays for one LDS read or one DMA piece): substep 0 carries the fragment
+    // reads of substep 1 and the first half of the next tile's DMA pieces, substep 1 the second half.
+    // sched_barrier(0) pins that order; fragments are double buffered in registers.
+    constexpr int NF = 2 * (TM + TN);                           // fragment reads per substep
+    constexpr int NM = 3 * TM * TN;                             // MFMAs per substep
+    h8 fr[2][NF];                                               // [substep][ah.., al.., bh.., bl..]
+    auto frag_read = [&](const char *st, int s, int f) {
+        const int which = f / 2, lo = f & 1;                    // f = 2*tile + (hi|lo), A tiles first
+        const int off = which < TM ? a_frag + which * 32 * ROW : b_frag + (which - TM) * 32 * ROW;
+        fr[s][f] = *reinterpret_cast<const h8 *>(st + off + (lo ? pos_lo[s] : pos_hi[s]));
+    };
+    auto mfma = [&](int s, int m) {
+        const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
+        const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
+        if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
+        else if (term == 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[i][j], 0, 0, 0);
+        else acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[i][j], 0, 0, 0);
+    };
+    // slot plan (one memory instruction after each MFMA): substep 0 first issues the DMA pieces of the next tile (as
+    // early as possible: they have to land before the next step), then the first fragments substep 1 needs; substep 1
+    // starts with the MFMAs of tile (0,0) and reads the fragments of the other tiles in its first slots.
+    constexpr int P0 = IN < NM - 4 ? IN : NM - 4;               // pieces issued in substep 0 (4 slots stay for fragments)
+    constexpr int F0 = NM - P0 < NF ? NM - P0 : NF;             // substep-1 fragments read during substep 0
+    static_assert(IN - P0 + NF - F0 <= NM, "not enough MFMA slots for the interleaved memory instructions");
+    // fragment order for substep 1: ah0, al0, bh0, bl0 (tile (0,0)), then bh1, bl1, ..., then ah1, al1, ...
+    auto frag_order = [&](int k) {
+        if (k < 2) return k;                                    // ah0, al0
+        if (k < 4) return 2 * TM + (k - 2);                     // bh0, bl0
+        const int r = k - 4, nb = 2 * (TN - 1);
+        return r < nb ? 2 * TM + 2 + r : 2 + (r - nb);          // remaining B tiles, then remaining A tiles
+    };
+    // one K step; REFILL (compile time) = a further tile exists and is fetched into the stage freed by step t-1
+    auto step = [&](int t, auto refill_c) {
+        constexpr bool REFILL = decltype(refill_c)::value;
         const char *st = ring + (t % NS) * STAGE;
+        const int fill_stage = (t + NS - 1) % NS;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            h8 ah[TM], al[TM], bh[TN], bl[TN];
+        for (int f = 0; f < NF; ++f) frag_read(st, 0, f);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_hi[s]);
-                al[i] = *reinterpret_cast<const h8 *>(st + a_frag + i * 32 * ROW + pos_lo[s]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_hi[s]);
-                bl[j] = *reinterpret_cast<const h8 *>(st + b_frag + j * 32 * ROW + pos_lo[s]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
-                }
+        for (int m = 0; m < NM; ++m) {
+            mfma(0, m);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < P0) { if (REFILL) piece(fill_stage, m); }
+            else if (m - P0 < F0) frag_read(st, 1, frag_order(m - P0));
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            mfma(1, m);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < NF - F0) frag_read(st, 1, frag_order(F0 + m));
+            else if (REFILL && P0 + (m - (NF - F0)) < IN) piece(fill_stage, P0 + (m - (NF - F0)));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (REFILL) advance_tile();
+    };
+    int t = 0;
+    unsigned long long c_wait = 0, c_bar = 0, c_body = 0, c_start = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
+    for (; t + NS - 1 < nk; ++t) {                             // steady state: NS-2 younger tiles stay in flight
+        unsigned long long t0 = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
+        wait_vmcnt<(NS - 2) * IN>();
+        unsigned long long t1 = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
+        __builtin_amdgcn_s_barrier();
+        unsigned long long t2 = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
+        step(t, std::true_type{});
+        if (YDS_TIMING) { unsigned long long t3 = __builtin_amdgcn_s_memtime(); c_wait += t1 - t0; c_bar += t2 - t1; c_body += t3 - t2; }
+    }
+    if (YDS_TIMING && lane == 0) {
+        unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&yds_prof[0], c_wait); atomicAdd(&yds_prof[1], c_bar); atomicAdd(&yds_prof[2], c_body);
+        atomicAdd(&yds_prof[3], t3 - c_start); atomicAdd(&yds_prof[4], (unsigned long long)t); atomicAdd(&yds_prof[5], 1ull);
+    }
+    for (; t < nk; ++t) {                                       // drain: nothing left to fetch
+        const int younger = nk - 1 - t;
+        if (younger >= 1 && NS >= 3) wait_vmcnt<(NS >= 3 ? IN : 0)>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        step(t, std::false_type{});
     }
     __syncthreads();                                            // every wave is done with the ring
 #pragma unroll
@@ -441,6 +509,14 @@ template <int BM, int BN> static void launch_cfg16(const ConvKernelArgs &k, hipS
 #define YDS_CALL(A, R) launch_inst16<BM, BN, A, R, FMT_F32>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
+    }
+}
+
+void conv_debug_prof(unsigned long long *out, bool reset) {
+    YDS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(yds_prof), sizeof(unsigned long long) * 8));
+    if (reset) {
+        unsigned long long z[8] = {};
+        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_prof), z, sizeof(z)));
     }
 }
 

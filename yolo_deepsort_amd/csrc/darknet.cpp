@@ -10,6 +10,7 @@
 //   * every layer keeps its own buffer for batch_max images (288 GB of HBM: no reuse games).
 #include "engine.h"
 #include "h16.h"
+#include "conv_common.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -684,6 +685,13 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     YDS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
+    YDS_API_END
+}
+int yds_debug_prof(uint64_t *out8, int reset) {
+    YDS_API_BEGIN
+    unsigned long long v[8];
+    yds::conv_debug_prof(v, reset != 0);
+    for (int i = 0; i < 8; ++i) out8[i] = v[i];
     YDS_API_END
 }
 int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int res_mode, const float *x_nhwc,
