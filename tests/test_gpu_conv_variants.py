@@ -65,6 +65,11 @@ CASES = [  # n, h, w, cin, cout, k, s, act, res_mode
     (1, 16, 8, 64, 64, 3, 1, "relu", 2),              # ReID basic block (residual before the activation)
     (5, 13, 13, 32, 512, 1, 1, "leaky", 0),
     (1, 40, 40, 32, 64, 3, 1, "mish", 1),
+    # 3x3 stride 1 at the detector's widths: tiles cross image boundaries, ragged tails, 1 / 2 / 4 channel groups
+    (3, 19, 19, 128, 128, 3, 1, "leaky", 0),
+    (2, 76, 76, 64, 128, 3, 1, "leaky", 1),
+    (5, 13, 13, 32, 96, 3, 1, "mish", 0),
+    (7, 8, 4, 256, 256, 3, 1, "relu", 2),
 ]
 
 
@@ -93,7 +98,12 @@ def test_every_conv_variant_vs_float64(math):
             want = _conv_ref(x, w, bias, k, s, ACT[act], res, res_mode)
             scale = float(np.abs(want).max())
             for v in mine:
-                got = _run(L, v, x, w, bias, k, s, ACT[act], res, res_mode)
+                try:
+                    got = _run(L, v, x, w, bias, k, s, ACT[act], res, res_mode)
+                except L.YdsError as e:
+                    # the window-resident kernel only takes 3x3 stride-1 layers; it must say so, not compute garbage
+                    assert "window-resident" in str(e) and not (k == 3 and s == 1), (names[v], str(e))
+                    continue
                 err = float(np.abs(got - want).max()) / scale
                 worst[names[v]] = max(worst.get(names[v], 0.0), err)
                 assert err < 1e-3, (names[v], (n, h, wd, cin, cout, k, s, act, res_mode), err)

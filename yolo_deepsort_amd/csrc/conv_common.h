@@ -11,6 +11,15 @@ namespace yds {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// split-fp16 ("f16x3") operand encoding shared by conv_f16x3.hip and conv_win.hip:
+//   x * A_SCALE = hi + lo / LO_SCALE,  w = hi + lo / LO_SCALE   (hi, lo fp16; see conv_f16x3.hip)
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr float A_SCALE = 1.f / 256.f, LO_SCALE = 2048.f;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 struct ConvKernelArgs {
     const float *x, *w, *bias, *res;
     float *y;
@@ -152,7 +161,10 @@ bool conv_direct_applicable(const ConvKernelArgs &k);
 void launch_conv_direct(const ConvKernelArgs &k, hipStream_t s);
 
 // split-fp16 path (conv_f16x3.hip)
-constexpr int kF16Variants = 8;            // 0-3 register-staged tiles, 4-7 LDS-DMA ring (pre-split inputs only)
+constexpr int kF16Variants = 9;            // 0-3 register-staged tiles, 4-7 LDS-DMA ring, 8 window-resident 3x3 (pre-split inputs only)
+// window-resident 3x3 stride-1 kernel (conv_win.hip)
+bool conv_win_applicable(const ConvKernelArgs &k);
+void launch_conv_win(ConvKernelArgs k, hipStream_t s);
 const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
 void conv_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING builds: wait / barrier / body / total cycles, steps, waves

@@ -22,8 +22,6 @@
 
 namespace yds {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWB = 144;                 // bytes per LDS row
 #ifndef YDS_PRIO_MODE
@@ -44,7 +42,6 @@ __device__ unsigned long long yds_prof[8];
 #ifndef YDS_F16_ABL
 #define YDS_F16_ABL 0                     // tools/ ablation builds: 1 no global loads in the K loop, 2 + no LDS stores, 3 no MFMA
 #endif
-constexpr float A_SCALE = 1.f / 256.f, LO_SCALE = 2048.f;
 
 __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 #pragma unroll
@@ -254,10 +251,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
 //            that iteration t-1 finished reading, then 24 MFMAs per wave on stage t % NS
 //   zero padding: out-of-image taps fetch from a zero page instead of branching
 //   WM x WN waves of 64 threads, each owning a 64x64 (TM = TN = 2) or smaller sub-tile.
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_void_t;
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int ZERO_PAGE_BYTES = 64 * 1024;                      // >= Cin * 4 + 128 for every layer (checked at launch)
 
@@ -523,7 +516,7 @@ void conv_debug_prof(unsigned long long *out, bool reset) {
 const char *conv_f16x3_variant_name(int v) {
     static const char *names[kF16Variants] = {"conv_igemm_f16x3<128,128>", "conv_igemm_f16x3<64,128>", "conv_igemm_f16x3<128,64>",
                                               "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,2x2,2>", "conv_igemm_f16x3_dma<256,128,4x2,3>",
-                                              "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>"};
+                                              "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>", "conv3x3_f16x3_win<256,128>"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
 }
 
@@ -536,7 +529,8 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s) {
         case 4: launch_cfg_dma<128, 128, 2, 2, 2>(k, s); break;
         case 5: launch_cfg_dma<256, 128, 4, 2, 3>(k, s); break;
         case 6: launch_cfg_dma<128, 256, 2, 4, 3>(k, s); break;
-        default: launch_cfg_dma<128, 128, 2, 2, 3>(k, s); break;
+        case 7: launch_cfg_dma<128, 128, 2, 2, 3>(k, s); break;
+        default: launch_conv_win(k, s); break;
     }
 }
 
