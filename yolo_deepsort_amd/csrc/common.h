@@ -94,7 +94,7 @@ struct ConvArgs {
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice
 int conv_default_variant(const ConvArgs &a);
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us);   // measured fastest variant
-constexpr int kF32Variants = 7, kDirectVariant = 16, kConvVariants = 17;   // ids 0-6: fp32 MFMA tiles, 7-15: f16x3 tiles, 16: direct RGB 3x3
+constexpr int kF32Variants = 7, kDirectVariant = 18, kConvVariants = 19;   // ids 0-6: fp32 MFMA tiles, 7-17: f16x3 tiles, 18: direct RGB 3x3
 enum ConvMath { MATH_F32 = 0, MATH_F16X3 = 1 };
 int conv_math();                 // process-wide arithmetic mode (env YDS_CONV_MATH=f32|f16x3, default f16x3)
 void set_conv_math(int m);

@@ -334,7 +334,7 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
         int v = atoi(f);
         bool dma = v >= kF32Variants + 4 && v != kDirectVariant;
         if (v == kDirectVariant && !conv_direct_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
-        if (v == kF32Variants + 8 && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
+        if (v >= kF32Variants + 8 && v != kDirectVariant && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (!(dma && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
     const std::string key = tune_key(a);
@@ -364,7 +364,8 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
         }
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
         if (v != kDirectVariant && v >= kF32Variants + 4 && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // LDS-DMA tiles need a pre-split input
-        if (v == kF32Variants + 8 && !conv_win_applicable(make_conv_args(a))) continue;
+        if (v >= kF32Variants + 8 && v != kDirectVariant && !conv_win_applicable(make_conv_args(a))) continue;
+        if (v > kF32Variants + 8 && v != kDirectVariant && a.y.c > 64) continue;       // 64-wide tiles are for 64-filter layers
         launch_conv(a, s, v);
         float t[3];
         for (int r = 0; r < 3; ++r) {

@@ -161,10 +161,10 @@ bool conv_direct_applicable(const ConvKernelArgs &k);
 void launch_conv_direct(const ConvKernelArgs &k, hipStream_t s);
 
 // split-fp16 path (conv_f16x3.hip)
-constexpr int kF16Variants = 9;            // 0-3 register-staged tiles, 4-7 LDS-DMA ring, 8 window-resident 3x3 (pre-split inputs only)
+constexpr int kF16Variants = 11;           // 0-3 register-staged tiles, 4-7 LDS-DMA ring, 8-10 window-resident 3x3 (pre-split inputs only)
 // window-resident 3x3 stride-1 kernel (conv_win.hip)
 bool conv_win_applicable(const ConvKernelArgs &k);
-void launch_conv_win(ConvKernelArgs k, hipStream_t s);
+void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s);   // shape 0: 256x128 (4x2 waves), 1: 256x64 (8x1), 2: 256x64 (4x2)
 const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
 void conv_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING builds: wait / barrier / body / total cycles, steps, waves

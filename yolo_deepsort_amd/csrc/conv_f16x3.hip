@@ -516,7 +516,8 @@ void conv_debug_prof(unsigned long long *out, bool reset) {
 const char *conv_f16x3_variant_name(int v) {
     static const char *names[kF16Variants] = {"conv_igemm_f16x3<128,128>", "conv_igemm_f16x3<64,128>", "conv_igemm_f16x3<128,64>",
                                               "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,2x2,2>", "conv_igemm_f16x3_dma<256,128,4x2,3>",
-                                              "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>", "conv3x3_f16x3_win<256,128>"};
+                                              "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>", "conv3x3_f16x3_win<256,128,4x2>",
+                                              "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
 }
 
@@ -530,7 +531,9 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s) {
         case 5: launch_cfg_dma<256, 128, 4, 2, 3>(k, s); break;
         case 6: launch_cfg_dma<128, 256, 2, 4, 3>(k, s); break;
         case 7: launch_cfg_dma<128, 128, 2, 2, 3>(k, s); break;
-        default: launch_conv_win(k, s); break;
+        case 8: launch_conv_win(k, 0, s); break;
+        case 9: launch_conv_win(k, 1, s); break;
+        default: launch_conv_win(k, 2, s); break;
     }
 }
 

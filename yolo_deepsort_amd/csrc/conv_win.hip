@@ -20,17 +20,19 @@ namespace yds {
 
 namespace {
 
-constexpr int BM = 256, BN = 128, WM = 4, WN = 2, NW = WM * WN, NT = NW * 64;
-constexpr int TM = 2, TN = 2;
+constexpr int BM = 256, NW = 8, NT = NW * 64;
 constexpr int NSB = 3;                         // filter-stage ring depth
 constexpr int ROW = 128;
-constexpr int B_STAGE = BN * ROW;
-constexpr int B_INST = BN / (8 * NW);          // filter DMA instructions per wave per stage (8 rows each)
 constexpr int APW = 7;                         // window DMA instructions per wave per channel group (8 rows each)
 constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 
-template <int ACT, int RES>
+// BN x (WM x WN waves): 128 x (4x2) = 64x64 accumulator tiles per wave; 64 x (8x1) / 64 x (4x2) for 64-filter layers
+template <int BN, int WM, int WN, int ACT, int RES>
 __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows) {
+    static_assert(WM * WN == NW, "eight waves");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int B_STAGE = BN * ROW;
+    constexpr int B_INST = BN / (8 * NW);      // filter DMA instructions per wave per stage (8 rows each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int WB = wrows * ROW;                                  // bytes per window buffer
     char *bring = smem + 2 * WB;                                 // [NSB][BN][128]
@@ -169,6 +171,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         constexpr bool REFILL = !(LAST && TAP >= 7);            // a step t+2 exists
         constexpr bool NEXT = !(LAST && TAP == 8);              // a step t+1 exists
         constexpr int TAP1 = (TAP + 1) % 9, TAP2 = (TAP + 2) % 9;
+        constexpr int OPS = (1 + B_INST + NF + NM - 1) / NM;    // memory operations per substep-1 slot
+        static_assert(NF <= NM, "not enough MFMA slots in substep 0");
         const int g1 = TAP + 1 >= 9 ? g + 1 : g, g2 = TAP + 2 >= 9 ? g + 1 : g;
         const char *bst = bring + (TAP % NSB) * B_STAGE, *bst1 = bring + ((TAP + 1) % NSB) * B_STAGE;
 #pragma unroll
@@ -186,12 +190,14 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         for (int m = 0; m < NM; ++m) {
             mfma(1, m);
             __builtin_amdgcn_sched_barrier(0);
-            if (m == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
-            else if (m - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + 2) % NSB, m - 1); }
-            else if (m - 1 - B_INST < NF) { if (NEXT) frag_read(bst1, 0, m - 1 - B_INST); }
+#pragma unroll
+            for (int o = m * OPS; o < (m + 1) * OPS; ++o) {     // memory operations of this slot
+                if (o == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
+                else if (o - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + 2) % NSB, o - 1); }
+                else if (o - 1 - B_INST < NF) { if (NEXT) frag_read(bst1, 0, o - 1 - B_INST); }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        static_assert(1 + B_INST + NF <= NM, "not enough MFMA slots in substep 1");
     };
     auto group = [&](int g, auto last_c) {
         step(g, std::integral_constant<int, 0>{}, last_c);
@@ -234,11 +240,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
 
-template <int ACT, int RES> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
+template <int BN, int WM, int WN, int ACT, int RES> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
     const int wrows = window_rows(k.W);
-    const size_t smem = 2ull * wrows * ROW + (size_t)NSB * B_STAGE + ROW;
+    const size_t smem = 2ull * wrows * ROW + (size_t)NSB * BN * ROW + ROW;
     static size_t attr_set = 0;
-    auto kern = conv3x3_f16x3_win<ACT, RES>;
+    auto kern = conv3x3_f16x3_win<BN, WM, WN, ACT, RES>;
     if (smem > attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = smem;
@@ -255,14 +261,24 @@ bool conv_win_applicable(const ConvKernelArgs &k) {
     const int wrows = window_rows(k.W);
     if (wrows > MAX_WROWS) return false;
     // the epilogue stages (BM/WM) x (BN+4) floats in the same LDS
-    return 2ull * wrows * ROW + (size_t)NSB * B_STAGE + ROW <= 160 * 1024 && (size_t)k.M * (k.ldx / 4) < (1ull << 32);
+    return 2ull * wrows * ROW + (size_t)NSB * 128 * ROW + ROW <= 160 * 1024 && (size_t)k.M * (k.ldx / 4) < (1ull << 32);
 }
 
-void launch_conv_win(ConvKernelArgs k, hipStream_t s) {
+void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
     if (!conv_win_applicable(k)) fail("conv: the window-resident kernel needs a 3x3 stride-1 layer with a pre-split input and W <= 95");
-#define YDS_CALL(A, R) launch_inst_win<A, R>(k, s)
-    YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+    if (shape == 0) {
+#define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R>(k, s)
+        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
+    } else if (shape == 1) {
+#define YDS_CALL(A, R) launch_inst_win<64, 8, 1, A, R>(k, s)
+        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+    } else {
+#define YDS_CALL(A, R) launch_inst_win<64, 4, 2, A, R>(k, s)
+        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+    }
 }
 
 }  // namespace yds
