@@ -12,14 +12,16 @@ from collections import OrderedDict
 
 
 def key_of(name):
-    m = re.match(r"void yds::(conv_igemm_f16x3_dma|conv_igemm_f16x3|conv_igemm_f32|conv3x3_rgb_direct)<([^>]*)>", name)
+    m = re.match(r"void yds::(?:\(anonymous namespace\)::)?(conv3x3_f16x3_win|conv_igemm_f16x3_dma|conv_igemm_f16x3|conv_igemm_f32|conv3x3_rgb_direct)<([^>]*)>", name)
     if not m:
         return None
     kind, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if kind == "conv_igemm_f16x3":
         return f"{kind}<{args[0]},{args[1]}>"
     if kind == "conv_igemm_f16x3_dma":
-        return f"{kind}<{args[0]},{args[1]},{args[2]}>"
+        return f"{kind}<{args[0]},{args[1]},{args[2]}x{args[3]},{args[4]}>"
+    if kind == "conv3x3_f16x3_win":
+        return f"{kind}<256,{args[0]},{args[1]}x{args[2]}>"
     if kind == "conv_igemm_f32":
         return f"{kind}<{','.join(args[:5])}>"
     return kind

@@ -115,6 +115,8 @@ void launch_yolo_decode(const View &head, float *out, int total_boxes, int box_o
                         const float *anchors_wh /*host, A pairs*/, int A, int img_h, int img_w, hipStream_t s);
 void launch_inject(const View &head, int image, const float *rows_dev, int n, int head_index, int num_classes,
                    float logit, hipStream_t s);
+void launch_inject_batch(const View &head, int batch, const float *table_dev, const int *offsets_dev, int max_rows, int head_index,
+                         int num_classes, float logit, hipStream_t s);
 // stretch-resize uint8 HWC frames to NHWC4 fp32 in [0,1] (4th channel 0)
 void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s);
 void launch_tile_resize(const uint8_t *frame, int w, const int *tiles_dev, int n_tiles, const View &y, hipStream_t s);

@@ -4,18 +4,25 @@
 // 608*608*32 outputs per image, not by arithmetic.  This kernel is a direct convolution on the vector ALU:
 // COUT/4 neighbouring lanes own one output pixel (4 output channels each, their 4x27 weights live in registers
 // for the whole kernel), so a wave's store instruction writes whole contiguous pixel rows (128 B / 256 B per
-// pixel) and the 9 input taps of a pixel are broadcast loads.  Arithmetic is a plain fp32 fma chain in both math
+// pixel); the input tile (8x32 pixels + halo) is staged in LDS and the 9 taps of a pixel are LDS broadcast reads.  Arithmetic is a plain fp32 fma chain in both math
 // modes (yolov3/yolov4 layer 0: yolo3/models/models.py:36-56; ReID stem: deep_sort/deep/model.py:52-60).
 #include "conv_common.h"
 
+#include <algorithm>
+
 namespace yds {
 
+constexpr int TH = 8, TW = 32;                      // output pixels per tile (rows x columns)
+
 template <int COUT, int ACT>
-__global__ __launch_bounds__(256) void conv3x3_rgb_direct(ConvKernelArgs p) {
+__global__ __launch_bounds__(256) void conv3x3_rgb_direct(ConvKernelArgs p, int tiles_y, int tiles_x, int n_tiles) {
     constexpr int QUADS = COUT / 4;                 // lanes per pixel
-    constexpr int PIX_PER_BLOCK = 256 / QUADS;
+    constexpr int PIX_PER_PASS = 256 / QUADS, PASSES = TH * TW / PIX_PER_PASS;
+    __shared__ float4 tile[TH + 2][TW + 2];         // input tile + halo (zero outside the image): the nine taps of a pixel
+                                                    // are LDS reads (4 cycles per wave instruction) instead of vector-memory
+                                                    // loads (16 cycles each on the texture path, where this kernel was bound)
     const int q = threadIdx.x % QUADS, slot = threadIdx.x / QUADS;
-    // this lane's weights: 4 output channels x 9 taps x 3 input channels (+ bias)
+    // this lane's weights: 4 output channels x 9 taps x 3 input channels (+ bias), loaded once (persistent blocks)
     float w[4][9][3], b[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -26,48 +33,70 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_direct(ConvKernelArgs p) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) w[o][t][c] = wr[t * 4 + c];
     }
-    const int HW = p.H * p.W;
-    for (int pix = blockIdx.x * PIX_PER_BLOCK + slot; pix < p.M; pix += gridDim.x * PIX_PER_BLOCK) {
-        const int img = pix / HW, rem = pix - img * HW;
-        const int oy = rem / p.W, ox = rem - oy * p.W;
-        float acc[4] = {b[0], b[1], b[2], b[3]};
-        // all nine taps are fetched branch-free (clamped address, zeroed afterwards) so the loads overlap
-        float4 tap[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int cy = min(max(iy, 0), p.H - 1), cx = min(max(ix, 0), p.W - 1);
-            float4 v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(img * p.H + cy) * p.W + cx) * p.ldx);
-            // arithmetic mask, not a select: a select lets the compiler sink the load into a branch again
-            // (nine serialized round trips); image values are finite, so v * 0 is an exact zero
-            const float keep = ok ? 1.f : 0.f;
-            tap[t] = make_float4(v.x * keep, v.y * keep, v.z * keep, 0.f);
+    for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+        __syncthreads();                            // previous tile fully consumed
+        for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 256) {
+            const int r = i / (TW + 2), c = i - r * (TW + 2);
+            const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.ldx);
+            tile[r][c] = v;
         }
+        __syncthreads();
+#pragma unroll 2
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int pi = pass * PIX_PER_PASS + slot, py = pi / TW, px = pi - py * TW;
+            const int oy = y0 + py, ox = x0 + px;
+            float acc[4] = {b[0], b[1], b[2], b[3]};
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t) {
+                const float4 v = tile[py + t / 3][px + t % 3];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                acc[o] = fmaf(tap[t].x, w[o][t][0], acc[o]);
-                acc[o] = fmaf(tap[t].y, w[o][t][1], acc[o]);
-                acc[o] = fmaf(tap[t].z, w[o][t][2], acc[o]);
+                for (int o = 0; o < 4; ++o) {
+                    acc[o] = fmaf(v.x, w[o][t][0], acc[o]);
+                    acc[o] = fmaf(v.y, w[o][t][1], acc[o]);
+                    acc[o] = fmaf(v.z, w[o][t][2], acc[o]);
+                }
             }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] = apply_act<ACT>(acc[o]);
-        store4(p.y + (size_t)pix * p.ldy, q * 4, p.fmt_y, acc);
+            for (int o = 0; o < 4; ++o) acc[o] = apply_act<ACT>(acc[o]);
+            const bool inside = oy < p.H && ox < p.W;
+            float *yp = p.y + ((size_t)(img * p.H + oy) * p.W + ox) * p.ldy;
+            if (p.fmt_y == FMT_H16) {
+                // lane pairs trade halves so that every lane issues ONE 16-byte store: the even lane writes the hi
+                // halves of both lanes' channels (8 consecutive fp16), the odd lane the lo halves
+                h16x4 hi, lo;
+                h16_encode4(acc, hi, lo);
+                const bool odd = q & 1;
+                union { h16x4 h; int i[2]; } send, recv;
+                send.h = odd ? hi : lo;
+                recv.i[0] = __shfl_xor(send.i[0], 1);
+                recv.i[1] = __shfl_xor(send.i[1], 1);
+                union { h16x4 h[2]; float4 f; } out;
+                out.h[0] = odd ? recv.h : hi;
+                out.h[1] = odd ? lo : recv.h;
+                const int c0 = (q & ~1) * 4;                                    // first channel of the pair
+                char *g = reinterpret_cast<char *>(yp + (c0 & ~31)) + (c0 & 31) * 2 + (odd ? 64 : 0);
+                if (inside) *reinterpret_cast<float4 *>(g) = out.f;
+            } else if (inside) {
+                *reinterpret_cast<float4 *>(yp + q * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
     }
 }
 
 template <int COUT> static void launch_direct_cout(const ConvKernelArgs &k, hipStream_t s) {
-    const int pix_per_block = 256 / (COUT / 4);
-    long blocks = ((long)k.M + pix_per_block - 1) / pix_per_block;
-    if (blocks > 256 * 16) blocks = 256 * 16;             // grid-stride: weights are loaded once per lane
-    dim3 grid((unsigned)blocks);
+    const int n_img = k.M / (k.H * k.W);
+    const int tiles_y = (k.H + TH - 1) / TH, tiles_x = (k.W + TW - 1) / TW, n_tiles = n_img * tiles_y * tiles_x;
+    dim3 grid((unsigned)std::min(n_tiles, 256 * 8));      // persistent blocks: the weights are loaded once per lane
     switch (k.act) {
-        case ACT_LEAKY: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_LEAKY>), grid, dim3(256), 0, s, k); break;
-        case ACT_MISH: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_MISH>), grid, dim3(256), 0, s, k); break;
-        case ACT_RELU: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_RELU>), grid, dim3(256), 0, s, k); break;
-        default: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_LINEAR>), grid, dim3(256), 0, s, k); break;
+        case ACT_LEAKY: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_LEAKY>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, n_tiles); break;
+        case ACT_MISH: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_MISH>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, n_tiles); break;
+        case ACT_RELU: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_RELU>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, n_tiles); break;
+        default: hipLaunchKernelGGL((conv3x3_rgb_direct<COUT, ACT_LINEAR>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, n_tiles); break;
     }
     YDS_HIP(hipGetLastError());
 }

@@ -427,13 +427,12 @@ void Darknet::run_graph(int batch) {
             View head = view(l.src, batch);
             int hidx = 0;
             for (int y : yolo_layers) { if (y == i) break; ++hidx; }
-            for (int b = 0; b < batch && inject_active; ++b) {
-                if (inject_set >= 0) {
-                    int o0 = inject_offsets[inject_set * batch_max + b], o1 = inject_offsets[inject_set * batch_max + b + 1];
-                    launch_inject(head, b, inject_table.p + (size_t)o0 * 9, o1 - o0, hidx, l.classes, inject_logit, stream);
-                } else {
+            if (inject_active && inject_set >= 0) {
+                launch_inject_batch(head, batch, inject_table.p, inject_offsets_dev.p + (size_t)inject_set * batch_max, inject_max_rows, hidx,
+                                    l.classes, inject_logit, stream);
+            } else {
+                for (int b = 0; b < batch && inject_active; ++b)
                     launch_inject(head, b, inject_rows[b].p, inject_n[b], hidx, l.classes, inject_logit, stream);
-                }
             }
             launch_yolo_decode(head, out.p, total_boxes, l.box_off, l.classes, l.anchors.data(), (int)l.anchors.size() / 2, img_h, img_w, stream);
         }
@@ -529,6 +528,10 @@ void Darknet::load_injection_sets(const float *rows, const int *offsets, int n_s
     inject_offsets.assign(offsets, offsets + (size_t)n_sets * batch_max + 1);
     inject_table.ensure((size_t)inject_offsets.back() * 9 + 9);
     inject_table.upload(rows, (size_t)inject_offsets.back() * 9, stream);
+    inject_offsets_dev.ensure(inject_offsets.size());
+    inject_offsets_dev.upload(inject_offsets.data(), inject_offsets.size(), stream);
+    inject_max_rows = 0;
+    for (size_t i = 0; i + 1 < inject_offsets.size(); ++i) inject_max_rows = std::max(inject_max_rows, inject_offsets[i + 1] - inject_offsets[i]);
     YDS_HIP(hipStreamSynchronize(stream));
     inject_logit = logit;
     inject_set = 0;

@@ -92,6 +92,8 @@ public:
     bool inject_active = false;
     DevBuf<float> inject_table;              // preloaded sets: rows of all (set, image) pairs
     std::vector<int> inject_offsets;         // n_sets * batch_max + 1 row offsets into inject_table
+    DevBuf<int> inject_offsets_dev;
+    int inject_max_rows = 0;
     int inject_set = -1;
     float inject_logit = 6.f;
     // conv timing (HIP events on this stream)

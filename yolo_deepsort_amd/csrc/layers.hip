@@ -276,6 +276,41 @@ void launch_inject(const View &head, int image, const float *rows_dev, int n, in
     YDS_HIP(hipGetLastError());
 }
 
+// the same for a whole batch in two launches: image = blockIdx.y, its rows are table[offsets[image] .. offsets[image + 1])
+__global__ void inject_clear_batch_kernel(float *head, int H, int W, int ld, int A, int attrs, float logit) {
+    const int total = H * W * A, image = blockIdx.y;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int a = idx % A, cell = idx / A;
+        head[((size_t)image * H * W + cell) * ld + a * attrs + 4] = -logit;
+    }
+}
+__global__ void inject_rows_batch_kernel(float *head, int H, int W, int ld, int attrs, const float *table, const int *offsets, int head_index,
+                                         float logit) {
+    const int image = blockIdx.y, o0 = offsets[image], n = offsets[image + 1] - o0, r = blockIdx.x;
+    if (r >= n) return;
+    const float *row = table + (size_t)(o0 + r) * 9;
+    if ((int)row[0] != head_index) return;
+    int a = (int)row[1], gy = (int)row[2], gx = (int)row[3], cls = (int)row[8];
+    float *cell = head + ((size_t)(image * H + gy) * W + gx) * ld + a * attrs;
+    for (int t = threadIdx.x; t < attrs; t += blockDim.x) {
+        float v;
+        if (t < 4) v = row[4 + t];
+        else if (t == 4) v = logit;
+        else v = (t - 5 == cls) ? logit : -logit;
+        cell[t] = v;
+    }
+}
+void launch_inject_batch(const View &head, int batch, const float *table_dev, const int *offsets_dev, int max_rows, int head_index,
+                         int num_classes, float logit, hipStream_t s) {
+    int attrs = num_classes + 5, A = head.c / attrs;
+    hipLaunchKernelGGL(inject_clear_batch_kernel, dim3(min(grid_for((size_t)head.h * head.w * A), 64), batch), dim3(256), 0, s, head.p, head.h,
+                       head.w, head.ld, A, attrs, logit);
+    if (max_rows > 0)
+        hipLaunchKernelGGL(inject_rows_batch_kernel, dim3(max_rows, batch), dim3(128), 0, s, head.p, head.h, head.w, head.ld, attrs, table_dev,
+                           offsets_dev, head_index, logit);
+    YDS_HIP(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------ bilinear u8
 // Spec (oracle/resize.py): half-pixel centres, clamped source index, fp32 lerp with every product and
 // sum rounded separately (no FMA), round-half-even to the uint8 grid.
