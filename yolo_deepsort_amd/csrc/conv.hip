@@ -247,6 +247,16 @@ int conv_default_variant(const ConvArgs &a) {
     return 2;
 }
 
+bool launch_conv_maxpool3s2(const ConvArgs &a, hipStream_t s) {
+    // make_conv_args derives M and the output size from a.y; describe the convolution's own output for that
+    ConvArgs c = a;
+    c.y.h = a.x.h; c.y.w = a.x.w;
+    ConvKernelArgs k = make_conv_args(c);
+    if (!conv_pool_applicable(k)) return false;
+    launch_conv_pool(k, s);
+    return true;
+}
+
 static int g_math = -1;
 int conv_math() {
     if (g_math < 0) {

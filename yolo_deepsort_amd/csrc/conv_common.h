@@ -159,6 +159,9 @@ ConvKernelArgs make_conv_args(const ConvArgs &a);
 // direct first-layer kernel (conv_first.hip)
 bool conv_direct_applicable(const ConvKernelArgs &k);
 void launch_conv_direct(const ConvKernelArgs &k, hipStream_t s);
+// ReID stem: the direct kernel fused with MaxPool2d(3, 2, 1); k.y is the pooled tensor
+bool conv_pool_applicable(const ConvKernelArgs &k);
+void launch_conv_pool(const ConvKernelArgs &k, hipStream_t s);
 
 // split-fp16 path (conv_f16x3.hip)
 constexpr int kF16Variants = 11;           // 0-3 register-staged tiles, 4-7 LDS-DMA ring, 8-10 window-resident 3x3 (pre-split inputs only)

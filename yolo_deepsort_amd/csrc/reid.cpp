@@ -144,10 +144,21 @@ void ReidNet::forward(int D) {
         conv_flops_last += conv_flops(a);
     };
     View x0 = mk(in, CROP_H, CROP_W, 4);
-    View stem = mk(bufs[0], CROP_H, CROP_W, 64);
-    run(0, x0, stem, ACT_RELU, nullptr, RES_NONE);
     View cur = mk(bufs[1], 64, 32, 64);
-    launch_maxpool(stem, cur, 3, 2, 1, false, stream);
+    {
+        // stem conv + BN + ReLU + MaxPool2d(3, 2, 1) (model.py:52-60) as one kernel; the unfused pair stays as fallback
+        const ConvW &c = convs[0];
+        ConvArgs a;
+        a.x = x0; a.y = cur; a.w = c.wt.p; a.w16 = c.wt16.p; a.bias = c.bias.p;
+        a.ksize = c.k; a.stride = c.stride; a.pad = c.pad; a.kpad = c.kpad; a.act = ACT_RELU;
+        if (!getenv("YDS_REID_UNFUSED") && launch_conv_maxpool3s2(a, stream)) {
+            conv_flops_last += 2.0 * D * CROP_H * CROP_W * 64 * 9 * 4;
+        } else {
+            View stem = mk(bufs[0], CROP_H, CROP_W, 64);
+            run(0, x0, stem, ACT_RELU, nullptr, RES_NONE);
+            launch_maxpool(stem, cur, 3, 2, 1, false, stream);
+        }
+    }
     int ci = 1, bi = 2, h = 64, w = 32;
     for (const StageDef &s : kStages) {
         if (s.down) { h /= 2; w /= 2; }
