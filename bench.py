@@ -160,6 +160,14 @@ def main():
                             frac_of_fp32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                             avg_launch_us=round(avg_us, 2), launches=int(dom["launches"]),
                             flops_per_launch=dom["flops"] / dom["launches"])
+            # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
+            # the committed rocprofv3 --pmc passes over this same command (tools/profile_bench.sh, PMC=1)
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_traffic_{args.config}.json")
+            if os.path.exists(tpath) and B == 16:
+                rec = json.load(open(tpath))["kernels"].get(dom["name"])
+                if rec:
+                    roofline["traffic"] = round(rec["hbm_bytes_per_launch"])
+                    roofline["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/" + os.path.basename(tpath) + ")"
 
     cpu = None
     if rank == 0 and args.cpu_frames > 0:

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of every conv tile variant from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+
+    python tools/traffic_from_pmc.py <FETCH_SIZE counter csv> <WRITE_SIZE counter csv>  > traffic.json
+Units / corrections as MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB-like units of 1024 B per
+count of TCC_EA0 64-byte requests / 16; FETCH_SIZE reports half of the bytes of wide coalesced reads (128-byte requests
+tallied at 64 B) and is doubled here; WRITE_SIZE is uncalibrated and reported as is."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from rocprof_agg import key_of  # noqa: E402
+
+
+def per_kernel(path, counter):
+    agg = defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = key_of(r["Kernel_Name"] if r["Kernel_Name"].startswith("void") else "void " + r["Kernel_Name"])
+        if k:
+            agg[k].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main(fetch_csv, write_csv):
+    f, w = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        fv, wv = f.get(k, []), w.get(k, [])
+        fetch = 2.0 * 1024.0 * sum(fv) / max(len(fv), 1)          # gfx950 correction: x2
+        write = 1024.0 * sum(wv) / max(len(wv), 1)
+        out[k] = {"launches": len(fv), "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                  "hbm_bytes_per_launch": fetch + write}
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950), WRITE_SIZE uncalibrated",
+               "kernels": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

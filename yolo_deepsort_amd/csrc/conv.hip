@@ -377,13 +377,16 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
         if (v >= kF32Variants + 8 && v != kDirectVariant && !conv_win_applicable(make_conv_args(a))) continue;
         if (v > kF32Variants + 8 && v != kDirectVariant && a.y.c > 64) continue;       // 64-wide tiles are for 64-filter layers
         launch_conv(a, s, v);
+        // median of three timings of four back-to-back launches each: single launches are too noisy (clock ramps) and a
+        // wrong pick costs several percent of the whole detector
         float t[3];
         for (int r = 0; r < 3; ++r) {
             YDS_HIP(hipEventRecord(e0, s));
-            launch_conv(a, s, v);
+            for (int k = 0; k < 4; ++k) launch_conv(a, s, v);
             YDS_HIP(hipEventRecord(e1, s));
             YDS_HIP(hipEventSynchronize(e1));
             YDS_HIP(hipEventElapsedTime(&t[r], e0, e1));
+            t[r] *= 0.25f;
         }
         float med = t[0] + t[1] + t[2] - fminf(t[0], fminf(t[1], t[2])) - fmaxf(t[0], fmaxf(t[1], t[2]));
         if (best < 0 || med < best_t) { best = v; best_t = med; }
