@@ -16,6 +16,10 @@
 // address of the DMA and again by the fragment reads; 16 consecutive rows hit 16 distinct bank slots at any base.
 #include "conv_common.h"
 
+#ifndef YDS_WIN_ABL
+#define YDS_WIN_ABL 0      // experiment builds: 1 no DMA in the K loop, 2 + no fragment reads, 3 no MFMA, 4 no barrier / vmcnt wait
+#endif
+
 namespace yds {
 
 namespace {
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     auto mfma = [&](int s, int m) {
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
         const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
+        if (YDS_WIN_ABL == 3) { acc1[i][j][term] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3]; return; }
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
         else if (term == 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[i][j], 0, 0, 0);
         else acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[i][j], 0, 0, 0);
@@ -179,11 +184,13 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         for (int m = 0; m < NM; ++m) {
             mfma(0, m);
             __builtin_amdgcn_sched_barrier(0);
-            if (m < NF) frag_read(bst, 1, frag_order(m));
+            if (m < NF && YDS_WIN_ABL != 2) frag_read(bst, 1, frag_order(m));
             __builtin_amdgcn_sched_barrier(0);
         }
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+        if (YDS_WIN_ABL != 4) {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
         if (NEXT) tap_addr(g1, TAP1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -192,9 +199,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int o = m * OPS; o < (m + 1) * OPS; ++o) {     // memory operations of this slot
-                if (o == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
-                else if (o - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + 2) % NSB, o - 1); }
-                else if (o - 1 - B_INST < NF) { if (NEXT) frag_read(bst1, 0, o - 1 - B_INST); }
+                constexpr bool DMA = YDS_WIN_ABL != 1 && YDS_WIN_ABL != 2;
+                if (o == 0) { if (DMA && !LAST && TAP < APW) a_piece(g + 1, TAP); }
+                else if (o - 1 < B_INST) { if (DMA && REFILL) b_piece(g2, TAP2, (TAP + 2) % NSB, o - 1); }
+                else if (o - 1 - B_INST < NF) { if (NEXT && YDS_WIN_ABL != 2) frag_read(bst1, 0, o - 1 - B_INST); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
