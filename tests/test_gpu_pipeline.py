@@ -9,8 +9,11 @@ F32 = np.float32
 DS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
 
 
-@pytest.mark.parametrize("name,size,batch", [("yolov3-tiny", 416, 4), ("yolov4-tiny", 416, 3)])
-def test_pipeline_matches_oracle_stream(name, size, batch):
+@pytest.mark.parametrize("name,size,batch,deep", [("yolov3-tiny", 416, 4, False), ("yolov4-tiny", 416, 3, False),
+                                                  ("yolov3-tiny", 416, 4, True)])
+def test_pipeline_matches_oracle_stream(name, size, batch, deep, monkeypatch):
+    # deep: the crowded-scene schedule (next batch's NMS + ReID started before this batch's association) forced on
+    monkeypatch.setenv("YDS_PIPE_DEEP_MIN", "0" if deep else "1000000")
     from oracle.darknet import DarknetOracle
     from oracle.pipeline import run_stream
     from yolo_deepsort_amd import _lib, pipeline as pl

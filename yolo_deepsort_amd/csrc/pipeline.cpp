@@ -15,6 +15,8 @@
 // under MFMA work.
 #include "engine.h"
 
+#include <stdlib.h>
+
 #include <chrono>
 
 namespace yds {
@@ -40,62 +42,100 @@ public:
         in_flight_batch = batch;
     }
 
+    // detections of one batch after NMS + class mask + p1p2Toxywh, ready for the extractor and the tracker
+    struct Dets {
+        std::vector<float> tlwh, payload;
+        std::vector<int> frame_of, first, n_det;
+        const uint8_t *frames = nullptr;
+        int batch = 0;
+        bool reid_in_flight = false;
+    };
+
+    // wait for the detector pass in flight, run NMS for all its frames, build the detection lists
+    void finish_detector(Dets &d, const uint8_t *frames_dev, int h, int w, int batch) {
+        const float sx = (float)((double)w / net->img_w), sy = (float)((double)h / net->img_h);
+        nms->launch(net->out.p, (size_t)net->total_boxes * net->attrs, batch, net->total_boxes, net->attrs, conf, nms_thres, sx, sy, 300,
+                    net->stream);
+        YDS_HIP(hipEventRecord(e_nms, net->stream));
+        YDS_HIP(hipEventSynchronize(e_nms));
+        in_flight = nullptr;
+        std::vector<float> det(300 * 6);
+        d.tlwh.clear(); d.payload.clear(); d.frame_of.clear();
+        d.first.assign(batch + 1, 0); d.n_det.assign(batch, 0);
+        d.frames = frames_dev; d.batch = batch; d.reid_in_flight = false;
+        for (int b = 0; b < batch; ++b) {
+            d.n_det[b] = nms->collect(b, det.data(), 300);
+            for (int i = 0; i < d.n_det[b]; ++i) {
+                const float *r = &det[i * 6];
+                bool keep = class_mask.empty();
+                for (int m : class_mask) keep |= (r[5] == (float)m);
+                if (!keep) continue;
+                d.tlwh.push_back(r[0]); d.tlwh.push_back(r[1]); d.tlwh.push_back(r[2] - r[0]); d.tlwh.push_back(r[3] - r[1]);
+                d.payload.push_back(r[5]);
+                d.frame_of.push_back(b);
+            }
+            d.first[b + 1] = (int)d.payload.size();
+        }
+        if ((int)d.payload.size() > reid->max_crops)
+            fail("pipeline: %d crops in one batch exceed the extractor capacity %d", (int)d.payload.size(), reid->max_crops);
+    }
+    // one ReID pass over the crops of the whole batch, asynchronous on the extractor's stream
+    void launch_reid(Dets &d, int h, int w) {
+        if (!d.payload.empty()) reid->embed_multi_dev(d.frames, h, w, d.tlwh.data(), d.frame_of.data(), (int)d.payload.size());
+        d.reid_in_flight = true;
+    }
+
     void step(const uint8_t *frames_dev, const uint8_t *next_frames_dev, int next_inject_set, int h, int w, int batch, int32_t *out6,
               int cap, int32_t *counts) {
         using clk = std::chrono::steady_clock;
         auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
         if (batch < 1 || batch > net->batch_max) fail("pipeline: batch %d outside [1,%d]", batch, net->batch_max);
         auto t_begin = clk::now();
-        if (in_flight != frames_dev || in_flight_batch != batch) launch_detector(frames_dev, h, w, batch);
-        in_flight = nullptr;
-        // NMS of every frame behind the detector, results into pinned host buffers
-        const float sx = (float)((double)w / net->img_w), sy = (float)((double)h / net->img_h);
-        nms->launch(net->out.p, (size_t)net->total_boxes * net->attrs, batch, net->total_boxes, net->attrs, conf, nms_thres, sx, sy, 300,
-                    net->stream);
-        YDS_HIP(hipEventRecord(e_nms, net->stream));
-        YDS_HIP(hipEventSynchronize(e_nms));
         float ms01 = 0, ms12 = 0;
-        YDS_HIP(hipEventElapsedTime(&ms01, e0, e1));
-        YDS_HIP(hipEventElapsedTime(&ms12, e1, e2));
+        const bool resumed = ahead.reid_in_flight && ahead.frames == frames_dev && ahead.batch == batch;
+        if (resumed) {
+            std::swap(cur, ahead);                                  // NMS done and ReID already running since the previous call
+            ahead.reid_in_flight = false;
+        } else {
+            ahead.reid_in_flight = false;
+            if (in_flight != frames_dev || in_flight_batch != batch) launch_detector(frames_dev, h, w, batch);
+            finish_detector(cur, frames_dev, h, w, batch);
+            YDS_HIP(hipEventElapsedTime(&ms01, e0, e1));
+            YDS_HIP(hipEventElapsedTime(&ms12, e1, e2));
+        }
         auto t_nms = clk::now();
-        // detector of the next batch goes in flight now: it overwrites `out` only after the NMS kernels above
+        // detector of the next batch goes in flight now: it overwrites `out` only after the NMS kernels of this batch
         if (next_frames_dev) {
             if (next_inject_set >= 0) net->select_injection_set(next_inject_set);      // bench-only logit injection
             launch_detector(next_frames_dev, h, w, batch);
         }
-        // host glue: class mask + p1p2Toxywh for all frames
-        std::vector<float> det(300 * 6);
-        tlwh.clear(); payload.clear(); frame_of.clear();
-        std::vector<int> first(batch + 1, 0), n_det(batch, 0);
-        for (int b = 0; b < batch; ++b) {
-            n_det[b] = nms->collect(b, det.data(), 300);
-            for (int i = 0; i < n_det[b]; ++i) {
-                const float *r = &det[i * 6];
-                bool keep = class_mask.empty();
-                for (int m : class_mask) keep |= (r[5] == (float)m);
-                if (!keep) continue;
-                tlwh.push_back(r[0]); tlwh.push_back(r[1]); tlwh.push_back(r[2] - r[0]); tlwh.push_back(r[3] - r[1]);
-                payload.push_back(r[5]);
-                frame_of.push_back(b);
-            }
-            first[b + 1] = (int)payload.size();
-        }
-        // one ReID pass over the crops of the whole batch (chunked by the extractor's capacity)
-        const int D_all = (int)payload.size();
-        if (D_all > reid->max_crops) fail("pipeline: %d crops in one batch exceed the extractor capacity %d", D_all, reid->max_crops);
+        if (!resumed) launch_reid(cur, h, w);
+        const int D_all = (int)cur.payload.size();
         if (D_all) {
-            reid->embed_multi_dev(frames_dev, h, w, tlwh.data(), frame_of.data(), D_all);
+            // the tracker reads its own copy so that the extractor can start on the next batch during the association
+            feat_cur.ensure((size_t)reid->max_crops * 512);
+            YDS_HIP(hipMemcpyAsync(feat_cur.p, reid->feat.p, (size_t)D_all * 512 * sizeof(float), hipMemcpyDeviceToDevice, reid->stream));
             YDS_HIP(hipStreamSynchronize(reid->stream));
         }
         auto t_reid = clk::now();
+        // Crowded scenes (the association of a batch takes long and is all small latency-bound kernels and host syncs):
+        // before associating, finish the next batch's detector + NMS and start its ReID pass, so that the matrix
+        // cores stay busy underneath.  Sparse scenes keep the simpler order (the detector alone covers the association).
+        const int deep_min = getenv("YDS_PIPE_DEEP_MIN") ? atoi(getenv("YDS_PIPE_DEEP_MIN")) : 64;    // detections per frame
+        if (next_frames_dev && D_all >= deep_min * batch) {
+            finish_detector(ahead, next_frames_dev, h, w, batch);
+            YDS_HIP(hipEventElapsedTime(&ms01, e0, e1));
+            YDS_HIP(hipEventElapsedTime(&ms12, e1, e2));
+            launch_reid(ahead, h, w);
+        }
         for (int b = 0; b < batch; ++b) {
-            if (n_det[b] == 0) { counts[b] = -1; continue; }       // detector returned None: tracker not called
-            const int D = first[b + 1] - first[b];
-            counts[b] = trk->step(tlwh.data() + (size_t)first[b] * 4, reid->feat.p + (size_t)first[b] * 512, true,
-                                  payload.data() + first[b], D, out6 + (size_t)b * cap * 6, cap);
+            if (cur.n_det[b] == 0) { counts[b] = -1; continue; }       // detector returned None: tracker not called
+            const int D = cur.first[b + 1] - cur.first[b];
+            counts[b] = trk->step(cur.tlwh.data() + (size_t)cur.first[b] * 4, feat_cur.p + (size_t)cur.first[b] * 512, true,
+                                  cur.payload.data() + cur.first[b], D, out6 + (size_t)b * cap * 6, cap);
         }
         auto t_end = clk::now();
-        stage_us[0] = ms01 * 1e3f; stage_us[1] = ms12 * 1e3f;
+        if (ms12 > 0) { stage_us[0] = ms01 * 1e3f; stage_us[1] = ms12 * 1e3f; }
         stage_us[2] = us(t_begin, t_nms); stage_us[3] = us(t_nms, t_reid); stage_us[4] = us(t_reid, t_end);
     }
 
@@ -105,8 +145,8 @@ public:
     float conf, nms_thres;
     std::vector<int32_t> class_mask;
     std::unique_ptr<NmsWorkspace> nms;
-    std::vector<float> tlwh, payload;
-    std::vector<int> frame_of;
+    Dets cur, ahead;                // this batch; the next batch when its ReID pass was started early
+    DevBuf<float> feat_cur;
     int next_inject_set = -1;      // bench-only: injection set of the prefetched detector pass
     const uint8_t *in_flight = nullptr;
     int in_flight_batch = 0;
