@@ -88,7 +88,7 @@ template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int 
 __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
     constexpr int ROWS = BM / WM, LD = BN + 4, C4 = BN / 4;        // staged rows, padded row length, float4 per row
     constexpr int RSTEP = NT / C4;                                   // rows covered by one sweep of the NT threads
-    static_assert(NT % C4 == 0, "tile width must divide the workgroup");
+    static_assert(NT % C4 == 0 && C4 % 2 == 0 && ROWS % RSTEP == 0, "tile width must divide the workgroup; lane pairs share a row");
     const int lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
     const int col = lane & 31, rsel = (lane >> 5) * 4;
     const int c4 = tid % C4, rr = tid / C4;
@@ -116,10 +116,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&
 #pragma unroll
         for (int r = rr; r < ROWS; r += RSTEP) {
             const int m = m0 + pass * ROWS + r;
-            if (m >= p.M || n >= p.Cout) continue;
+            const bool live = m < p.M && n < p.Cout;             // no early exit: lane pairs trade halves below
             float4 v = *reinterpret_cast<const float4 *>(stage + r * LD + c4 * 4);
             float rs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (RES != RES_NONE) {
+            if (RES != RES_NONE && live) {
                 const float *rp = p.res + (size_t)m * p.ldr;
                 if (p.fmt_r == FMT_H16) h16_load4(rp, n, rs);                  // H16 tensors have Cout % 32 == 0
                 else if (n_vec) { float4 t = *reinterpret_cast<const float4 *>(rp + n); rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
@@ -133,9 +133,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&
                 if (RES == RES_AFTER_ACT) o[k] += rs[k];
             }
             float *yp = p.y + (size_t)m * p.ldy;
-            if (p.fmt_y == FMT_H16) h16_store4(yp, n, o);
-            else if (n_vec) *reinterpret_cast<float4 *>(yp + n) = make_float4(o[0], o[1], o[2], o[3]);
-            else { yp[n] = o[0]; if (n + 1 < p.Cout) yp[n + 1] = o[1]; if (n + 2 < p.Cout) yp[n + 2] = o[2]; }
+            if (p.fmt_y == FMT_H16) {
+                // neighbouring lanes hold neighbouring channel quads of the same pixel: they trade halves so that each lane
+                // issues ONE 16-byte store (even lane: 8 hi halves, odd lane: 8 lo halves) instead of two 8-byte ones
+                h16x4 hi, lo;
+                h16_encode4(o, hi, lo);
+                const bool odd = c4 & 1;
+                union { h16x4 h; int i[2]; } send, recv;
+                send.h = odd ? hi : lo;
+                recv.i[0] = __shfl_xor(send.i[0], 1);
+                recv.i[1] = __shfl_xor(send.i[1], 1);
+                union { h16x4 h[2]; float4 f; } out;
+                out.h[0] = odd ? recv.h : hi;
+                out.h[1] = odd ? lo : recv.h;
+                const int nq = n & ~7;                                          // first channel of the lane pair
+                char *g = reinterpret_cast<char *>(yp + (nq & ~31)) + (nq & 31) * 2 + (odd ? 64 : 0);
+                if (live) *reinterpret_cast<float4 *>(g) = out.f;
+            } else if (live) {
+                if (n_vec) *reinterpret_cast<float4 *>(yp + n) = make_float4(o[0], o[1], o[2], o[3]);
+                else { yp[n] = o[0]; if (n + 1 < p.Cout) yp[n + 1] = o[1]; if (n + 2 < p.Cout) yp[n + 2] = o[2]; }
+            }
         }
         if (pass + 1 < WM) __syncthreads();
     }
