@@ -70,6 +70,7 @@ CASES = [  # n, h, w, cin, cout, k, s, act, res_mode
     (2, 76, 76, 64, 128, 3, 1, "leaky", 1),
     (5, 13, 13, 32, 96, 3, 1, "mish", 0),
     (7, 8, 4, 256, 256, 3, 1, "relu", 2),
+    (1, 12, 304, 32, 64, 3, 1, "leaky", 1),           # one channel group: single window buffer, wide image
 ]
 
 

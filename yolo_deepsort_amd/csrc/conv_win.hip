@@ -11,13 +11,14 @@
 //   K order: channel group outer, tap inner (weights stay [Cout][kh][kw][Cin]: chunk index tap*G + g)
 //   global->LDS instructions per wave and K step: 2 (filters) + <= 1 (next group's window), against 6-8 before
 //   LDS: two window buffers (double buffered across channel groups) + 3 filter stages + the zero row <= 160 KB, one
-//   512-thread workgroup per CU (8 waves, 4x2, 64x64 accumulator tiles), W <= 95
+//   512-thread workgroup per CU (8 waves, 4x2, 64x64 accumulator tiles), W <= 95 (single-group layers: one window
+//   buffer, W <= 318)
 // Same swizzle as the DMA kernel: row r keeps its 16-byte chunk c at position c ^ ((r >> 1) & 7), applied on the source
 // address of the DMA and again by the fragment reads; 16 consecutive rows hit 16 distinct bank slots at any base.
 #include "conv_common.h"
 
 #ifndef YDS_WIN_ABL
-#define YDS_WIN_ABL 0      // experiment builds: 1 no DMA in the K loop, 2 + no fragment reads, 3 no MFMA, 4 no barrier / vmcnt wait
+#define YDS_WIN_ABL 0      // experiment builds: 1 no DMA in the K loop, 2 + no fragment reads, 3 no MFMA, 4 no barrier / vmcnt wait, 5 no K loop
 #endif
 
 namespace yds {
@@ -32,15 +33,15 @@ constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 
 // BN x (WM x WN waves): 128 x (4x2) = 64x64 accumulator tiles per wave; 64 x (8x1) / 64 x (4x2) for 64-filter layers
 template <int BN, int WM, int WN, int ACT, int RES>
-__global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows) {
+__global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows, int nbuf) {
     static_assert(WM * WN == NW, "eight waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int B_STAGE = BN * ROW;
     constexpr int B_INST = BN / (8 * NW);      // filter DMA instructions per wave per stage (8 rows each)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int WB = wrows * ROW;                                  // bytes per window buffer
-    char *bring = smem + 2 * WB;                                 // [NSB][BN][128]
-    const int zoff = 2 * WB + NSB * B_STAGE;                     // zero row
+    char *bring = smem + nbuf * WB;                              // [NSB][BN][128]; nbuf = 2 window buffers, 1 for single-group layers
+    const int zoff = nbuf * WB + NSB * B_STAGE;                  // zero row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -56,19 +57,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 
     const int W = p.W, G = p.Cin / 32;
     const int drow = lane >> 3, dpos = lane & 7;
-    // window pieces of this wave: piece pc covers window rows pc*8 .. pc*8+7; row j <-> flat input pixel m0 - W - 1 + j
-    // (clamped into the tensor: rows outside it are never read unmasked); offsets in 16-byte units
-    unsigned a_off16[APW];
-    int a_dst[APW];
+    // window pieces: piece pc covers window rows pc*8 .. pc*8+7, wave w issues pieces w, w+8, ...; row j <-> flat input
+    // pixel m0 - W - 1 + j (clamped into the tensor: rows outside it are never read unmasked); offsets in 16-byte units
     const int npieces = wrows / 8;
-#pragma unroll
-    for (int k = 0; k < APW; ++k) {
-        const int pc = min(k * NW + wave, npieces - 1);
-        const int j = pc * 8 + drow;
-        const int f = min(max(m0 - W - 1 + j, 0), p.M - 1);
-        a_off16[k] = (unsigned)f * (unsigned)(p.ldx / 4) + (unsigned)(dpos ^ ((j >> 1) & 7));
-        a_dst[k] = pc * 8 * ROW;
-    }
     unsigned w_off16[B_INST];
 #pragma unroll
     for (int b = 0; b < B_INST; ++b) {
@@ -77,8 +68,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     }
     const char *x_bytes = reinterpret_cast<const char *>(p.x), *w_bytes = reinterpret_cast<const char *>(p.w);
     auto a_piece = [&](int g, int k) {                           // window of channel group g -> buffer g & 1
-        const char *src = x_bytes + (size_t)g * 128 + ((size_t)a_off16[k] << 4);
-        __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(smem + (g & 1) * WB + a_dst[k]), 16, 0, 0);
+        const int pc = min(k * NW + wave, npieces - 1);        // surplus instructions repeat the last piece (same data, same place)
+        const int j = pc * 8 + drow;
+        const int f = min(max(m0 - W - 1 + j, 0), p.M - 1);
+        const unsigned off16 = (unsigned)f * (unsigned)(p.ldx / 4) + (unsigned)(dpos ^ ((j >> 1) & 7));
+        const char *src = x_bytes + (size_t)g * 128 + ((size_t)off16 << 4);
+        __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(smem + (g & 1) * WB + pc * 8 * ROW), 16, 0, 0);
     };
     auto b_piece = [&](int g, int tap, int stage, int b) {       // filter rows of K chunk (tap, g)
         const char *src = w_bytes + (size_t)(tap * G + g) * 128 + ((size_t)w_off16[b] << 4);
@@ -220,8 +215,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     };
 
     // prologue: window of group 0, filter stages of steps 0 and 1, fragments of step 0 / substep 0
-#pragma unroll
-    for (int k = 0; k < APW; ++k) a_piece(0, k);
+    for (int k = 0; k < (npieces + NW - 1) / NW; ++k) a_piece(0, k);
 #pragma unroll
     for (int b = 0; b < B_INST; ++b) b_piece(0, 0, 0, b);
 #pragma unroll
@@ -233,8 +227,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     for (int f = 0; f < NF; ++f) frag_read(bring, 0, f);
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int g = 0; g + 1 < G; ++g) group(g, std::false_type{});
-    group(G - 1, std::true_type{});
+    if (YDS_WIN_ABL != 5) {                                     // ablation 5: prologue + epilogue only
+        for (int g = 0; g + 1 < G; ++g) group(g, std::false_type{});
+        group(G - 1, std::true_type{});
+    }
 
     __syncthreads();                                            // every wave is done with the window and the ring
 #pragma unroll
@@ -249,8 +245,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
 
 template <int BN, int WM, int WN, int ACT, int RES> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
-    const int wrows = window_rows(k.W);
-    const size_t smem = 2ull * wrows * ROW + (size_t)NSB * BN * ROW + ROW;
+    const int wrows = window_rows(k.W), nbuf = k.Cin == 32 ? 1 : 2;
+    const size_t smem = (size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW;
     static size_t attr_set = 0;
     auto kern = conv3x3_f16x3_win<BN, WM, WN, ACT, RES>;
     if (smem > attr_set) {
@@ -258,7 +254,7 @@ template <int BN, int WM, int WN, int ACT, int RES> void launch_inst_win(ConvKer
         attr_set = smem;
     }
     dim3 grid(plan_tile_map(k, BM, BN));
-    hipLaunchKernelGGL(kern, grid, dim3(NT), smem, s, k, wrows);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), smem, s, k, wrows, nbuf);
     YDS_HIP(hipGetLastError());
 }
 
@@ -266,14 +262,16 @@ template <int BN, int WM, int WN, int ACT, int RES> void launch_inst_win(ConvKer
 
 bool conv_win_applicable(const ConvKernelArgs &k) {
     if (!(k.ksize == 3 && k.stride == 1 && k.pad == 1 && k.fmt_x == FMT_H16 && k.Cin % 32 == 0 && k.H == k.Ho && k.W == k.Wo)) return false;
-    const int wrows = window_rows(k.W);
-    if (wrows > MAX_WROWS) return false;
-    // the epilogue stages (BM/WM) x (BN+4) floats in the same LDS
-    return 2ull * wrows * ROW + (size_t)NSB * 128 * ROW + ROW <= 160 * 1024 && (size_t)k.M * (k.ldx / 4) < (1ull << 32);
+    const int wrows = window_rows(k.W), nbuf = k.Cin == 32 ? 1 : 2;
+    // several channel groups: the next group's window is fetched by at most APW instructions per wave while this one is
+    // consumed (two buffers); a single group needs one buffer only, which admits much wider images
+    if (nbuf == 2 && wrows > MAX_WROWS) return false;
+    // (the epilogue stages (BM/WM) x (BN+4) floats in the same LDS)
+    return (size_t)nbuf * wrows * ROW + (size_t)NSB * 128 * ROW + ROW <= 160 * 1024 && (size_t)k.M * (k.ldx / 4) < (1ull << 32);
 }
 
 void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
-    if (!conv_win_applicable(k)) fail("conv: the window-resident kernel needs a 3x3 stride-1 layer with a pre-split input and W <= 95");
+    if (!conv_win_applicable(k)) fail("conv: the window-resident kernel needs a 3x3 stride-1 layer with a pre-split input and W <= 95 (W <= 318 for 32 input channels)");
     if (shape == 0) {
 #define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
