@@ -12,6 +12,8 @@
 
 namespace yds {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int TH = 8, TW = 32;                      // output pixels per tile (rows x columns)
 
 template <int COUT, int ACT>
@@ -23,44 +25,60 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_direct(ConvKernelArgs p, int 
                                                     // loads (16 cycles each on the texture path, where this kernel was bound)
     const int q = threadIdx.x % QUADS, slot = threadIdx.x / QUADS;
     // this lane's weights: 4 output channels x 9 taps x 3 input channels (+ bias), loaded once (persistent blocks)
-    float w[4][9][3], b[4];
+    f32x2 w[2][9][3], b[2];                         // channel pairs: the fma chain runs on v_pk_fma_f32 (two channels per instruction)
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const float *wr = p.w + (size_t)(q * 4 + o) * p.Kpad;
-        b[o] = p.bias[q * 4 + o];
+        b[o / 2][o % 2] = p.bias[q * 4 + o];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) w[o][t][c] = wr[t * 4 + c];
+            for (int c = 0; c < 3; ++c) w[o / 2][t][c][o % 2] = wr[t * 4 + c];
     }
+    // the next tile's input is fetched into registers while this tile is computed (two 16-byte loads per thread)
+    constexpr int LOADS = ((TH + 2) * (TW + 2) + 255) / 256;
+    float4 nxt[LOADS];
+    auto fetch = [&](int tl) {
+        const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
+        const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
+#pragma unroll
+        for (int l = 0; l < LOADS; ++l) {
+            const int i = threadIdx.x + l * 256;
+            const int r = i / (TW + 2), c = i - r * (TW + 2);
+            const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+            nxt[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < (TH + 2) * (TW + 2) && tl < n_tiles && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                nxt[l] = *reinterpret_cast<const float4 *>(p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.ldx);
+        }
+    };
+    fetch(blockIdx.x);
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
         const int y0 = (rem / tiles_x) * TH, x0 = (rem % tiles_x) * TW;
         __syncthreads();                            // previous tile fully consumed
-        for (int i = threadIdx.x; i < (TH + 2) * (TW + 2); i += 256) {
-            const int r = i / (TW + 2), c = i - r * (TW + 2);
-            const int iy = y0 - 1 + r, ix = x0 - 1 + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const float4 *>(p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.ldx);
-            tile[r][c] = v;
+#pragma unroll
+        for (int l = 0; l < LOADS; ++l) {
+            const int i = threadIdx.x + l * 256;
+            if (i < (TH + 2) * (TW + 2)) (&tile[0][0])[i] = nxt[l];
         }
         __syncthreads();
+        fetch(tl + gridDim.x);
 #pragma unroll 2
         for (int pass = 0; pass < PASSES; ++pass) {
             const int pi = pass * PIX_PER_PASS + slot, py = pi / TW, px = pi - py * TW;
             const int oy = y0 + py, ox = x0 + px;
-            float acc[4] = {b[0], b[1], b[2], b[3]};
+            f32x2 a2[2] = {b[0], b[1]};
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float4 v = tile[py + t / 3][px + t % 3];
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    acc[o] = fmaf(v.x, w[o][t][0], acc[o]);
-                    acc[o] = fmaf(v.y, w[o][t][1], acc[o]);
-                    acc[o] = fmaf(v.z, w[o][t][2], acc[o]);
+                for (int o = 0; o < 2; ++o) {
+                    a2[o] = __builtin_elementwise_fma(f32x2{v.x, v.x}, w[o][t][0], a2[o]);
+                    a2[o] = __builtin_elementwise_fma(f32x2{v.y, v.y}, w[o][t][1], a2[o]);
+                    a2[o] = __builtin_elementwise_fma(f32x2{v.z, v.z}, w[o][t][2], a2[o]);
                 }
             }
+            float acc[4] = {a2[0][0], a2[0][1], a2[1][0], a2[1][1]};
 #pragma unroll
             for (int o = 0; o < 4; ++o) acc[o] = apply_act<ACT>(acc[o]);
             const bool inside = oy < p.H && ox < p.W;
@@ -114,15 +132,15 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_pool(ConvKernelArgs p, int Hp
     constexpr int IR = 2 * PTH + 3, IC = 2 * PTW + 3;           // input tile incl. both halos
     __shared__ float4 tile[IR][IC];
     const int q = threadIdx.x % QUADS, slot = threadIdx.x / QUADS;
-    float w[4][9][3], b[4];
+    f32x2 w[2][9][3], b[2];                         // channel pairs: the fma chain runs on v_pk_fma_f32 (two channels per instruction)
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
         const float *wr = p.w + (size_t)(q * 4 + o) * p.Kpad;
-        b[o] = p.bias[q * 4 + o];
+        b[o / 2][o % 2] = p.bias[q * 4 + o];
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) w[o][t][c] = wr[t * 4 + c];
+            for (int c = 0; c < 3; ++c) w[o / 2][t][c][o % 2] = wr[t * 4 + c];
     }
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
@@ -148,17 +166,18 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_pool(ConvKernelArgs p, int Hp
                 const int dy = d / 3, dx = d - dy * 3;
                 const int cy = 2 * Py - 1 + dy, cx = 2 * Px - 1 + dx;           // convolution output position
                 const bool valid = (unsigned)cy < (unsigned)p.H && (unsigned)cx < (unsigned)p.W;
-                float acc[4] = {b[0], b[1], b[2], b[3]};
+                f32x2 a2[2] = {b[0], b[1]};
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const float4 v = tile[2 * ppy + dy + t / 3][2 * ppx + dx + t % 3];
 #pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        acc[o] = fmaf(v.x, w[o][t][0], acc[o]);
-                        acc[o] = fmaf(v.y, w[o][t][1], acc[o]);
-                        acc[o] = fmaf(v.z, w[o][t][2], acc[o]);
+                    for (int o = 0; o < 2; ++o) {
+                        a2[o] = __builtin_elementwise_fma(f32x2{v.x, v.x}, w[o][t][0], a2[o]);
+                        a2[o] = __builtin_elementwise_fma(f32x2{v.y, v.y}, w[o][t][1], a2[o]);
+                        a2[o] = __builtin_elementwise_fma(f32x2{v.z, v.z}, w[o][t][2], a2[o]);
                     }
                 }
+                const float acc[4] = {a2[0][0], a2[0][1], a2[1][0], a2[1][1]};
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     const float a = apply_act<ACT>(acc[o]);
