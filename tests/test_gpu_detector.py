@@ -250,3 +250,22 @@ def test_resize_front_end_bit_exact():
         got = net.get_input(1)
         want = resize_bilinear_u8(frame, (416, 416)).astype(F32).transpose(2, 0, 1)[None] / F32(255.)
         assert np.array_equal(got, want), (h, w)
+
+
+def test_lane_split_matches_single_stream(monkeypatch):
+    """run_graph enqueues a batch as independent image ranges on several streams: same results as one stream
+    (uneven split 5 + 4, injection and decode offsets included), and every image equals its batch-of-one result."""
+    cfg = cfgs.cfg_text("yolov3-tiny")
+    rng = np.random.RandomState(11)
+    x = rng.uniform(0, 1, (9, 3, 416, 416)).astype(F32)
+    outs = {}
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("YDS_DET_LANES", lanes)
+        net, _ = _nets(cfg, 416, 0, obj_bias=-1.0, batch_max=9)
+        outs[lanes] = np.asarray(net(x))
+    assert outs["1"].shape == (9, 2535, 85)
+    _close(outs["2"], outs["1"], rtol=1e-4, atol=1e-4, msg="lanes")
+    monkeypatch.setenv("YDS_DET_LANES", "1")
+    net1, _ = _nets(cfg, 416, 0, obj_bias=-1.0, batch_max=1)
+    for b in (0, 4, 5, 8):
+        _close(outs["2"][b:b + 1], np.asarray(net1(x[b:b + 1])), rtol=1e-4, atol=1e-4, msg=f"image {b}")

@@ -282,6 +282,7 @@ View Darknet::view(int i, int batch) const {
     v.n = batch; v.h = l.h; v.w = l.w; v.c = l.c;
     if (l.type == "route" && l.refs.size() > 1) {
         v.p = storage[i].buf.p; v.ld = storage[i].ld; v.fmt = storage[i].fmt;
+        v.p += (size_t)lane_img0 * l.h * l.w * v.ld;
         return v;
     }
     const Storage &st = storage[r];
@@ -295,12 +296,13 @@ View Darknet::view(int i, int batch) const {
         v.ld = st.ld;
         v.fmt = st.fmt;
     }
+    v.p += (size_t)lane_img0 * l.h * l.w * v.ld;                // image range of the lane being enqueued (run_graph)
     return v;
 }
 
 View Darknet::input_view(int batch) const {
     View v;
-    v.p = input.p; v.n = batch; v.h = img_h; v.w = img_w; v.c = 4; v.ld = 4;
+    v.p = input.p + (size_t)lane_img0 * img_h * img_w * 4; v.n = batch; v.h = img_h; v.w = img_w; v.c = 4; v.ld = 4;
     return v;
 }
 
@@ -388,10 +390,47 @@ void Darknet::autotune(int batch) {
     }
 }
 
+// The detector is stateless per image, so a batch is enqueued as LANES independent image ranges on their own streams:
+// while one lane sits in the tail of a layer (a partial last round of workgroups, a burst of epilogue stores) the other
+// lane's kernels could fill the idle CUs.  Measured (cfg2, 16 frames): 1 lane 1275 frames/s, 2 lanes 1087, 4 lanes 964 -
+// lanes that start together run the same layers in lock-step and contend instead of complementing each other (two
+// desynchronised PROCESSES with half the batch each did gain 11 %), so the default is one lane and YDS_DET_LANES opts in.
+// Results are unchanged by the split (every image sees exactly the same kernels).
 void Darknet::run_graph(int batch) {
     if (batch < 1 || batch > batch_max) fail("forward: batch %d outside [1,%d]", batch, batch_max);
     if (math != conv_math()) fail("forward: this network was planned for conv math %d, current mode is %d (re-create it)", math, conv_math());
-    autotune(batch);
+    int lanes = getenv("YDS_DET_LANES") ? atoi(getenv("YDS_DET_LANES")) : 1;     // opt-in: see the note above
+    while (lanes > 1 && batch / lanes < 4) --lanes;             // at least four images per lane
+    if (lanes < 1) lanes = 1;
+    if (lanes == 1) { run_lane(0, batch, stream); return; }
+    while ((int)lane_streams.size() < lanes - 1) {
+        hipStream_t st; hipEvent_t ev;
+        YDS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        YDS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        lane_streams.push_back(st); lane_done.push_back(ev);
+    }
+    if (!lane_fork) YDS_HIP(hipEventCreateWithFlags(&lane_fork, hipEventDisableTiming));
+    // every lane count is tuned before anything is enqueued (tuning launches on the main stream)
+    const int per = (batch + lanes - 1) / lanes;
+    YDS_HIP(hipEventRecord(lane_fork, stream));                 // input resized, previous consumers of `out` enqueued
+    for (int k = 0; k < lanes; ++k) {
+        const int first = k * per, cnt = std::min(per, batch - first);
+        if (cnt <= 0) break;
+        // with per-launch event timing (roofline pass) the lanes run one after the other on the main stream
+        hipStream_t st = (k == 0 || time_convs) ? stream : lane_streams[k - 1];
+        if (st != stream) YDS_HIP(hipStreamWaitEvent(st, lane_fork, 0));
+        run_lane(first, cnt, st);
+        if (st != stream) {
+            YDS_HIP(hipEventRecord(lane_done[k - 1], st));
+            YDS_HIP(hipStreamWaitEvent(stream, lane_done[k - 1], 0));
+        }
+    }
+}
+
+void Darknet::run_lane(int first, int batch, hipStream_t stream) {
+    autotune(batch);                                            // (tuning launches use the main stream; cached per image count)
+    lane_img0 = first;
+    struct Reset { int &v; ~Reset() { v = 0; } } reset{lane_img0};
     for (int i = 0; i < (int)layers.size(); ++i) {
         Layer &l = layers[i];
         if (l.type == "convolutional") {
@@ -428,13 +467,13 @@ void Darknet::run_graph(int batch) {
             int hidx = 0;
             for (int y : yolo_layers) { if (y == i) break; ++hidx; }
             if (inject_active && inject_set >= 0) {
-                launch_inject_batch(head, batch, inject_table.p, inject_offsets_dev.p + (size_t)inject_set * batch_max, inject_max_rows, hidx,
+                launch_inject_batch(head, batch, inject_table.p, inject_offsets_dev.p + (size_t)inject_set * batch_max + first, inject_max_rows, hidx,
                                     l.classes, inject_logit, stream);
             } else {
                 for (int b = 0; b < batch && inject_active; ++b)
-                    launch_inject(head, b, inject_rows[b].p, inject_n[b], hidx, l.classes, inject_logit, stream);
+                    launch_inject(head, b, inject_rows[first + b].p, inject_n[first + b], hidx, l.classes, inject_logit, stream);
             }
-            launch_yolo_decode(head, out.p, total_boxes, l.box_off, l.classes, l.anchors.data(), (int)l.anchors.size() / 2, img_h, img_w, stream);
+            launch_yolo_decode(head, out.p + (size_t)first * total_boxes * attrs, total_boxes, l.box_off, l.classes, l.anchors.data(), (int)l.anchors.size() / 2, img_h, img_w, stream);
         }
     }
 }

@@ -104,6 +104,11 @@ public:
 
 private:
     void run_graph(int batch);
+    void run_lane(int first, int batch, hipStream_t st);      // layers over images [first, first + batch) on one stream
+    int lane_img0 = 0;                                        // image offset applied by view() / input_view() while a lane is enqueued
+    std::vector<hipStream_t> lane_streams;
+    std::vector<hipEvent_t> lane_done;
+    hipEvent_t lane_fork = nullptr;
 };
 
 // --------------------------------------------------------------------------------------------- NMS

@@ -25,19 +25,30 @@ class Pipeline {
 public:
     Pipeline(Darknet *net, ReidNet *reid, TrackerIface *trk, float conf, float nms_iou, const int32_t *mask, int n_mask)
         : net(net), reid(reid), trk(trk), conf(conf), nms_thres(nms_iou), class_mask(mask, mask + n_mask) {
-        for (hipEvent_t *e : {&e0, &e1, &e2, &e_nms}) YDS_HIP(hipEventCreate(e));
-        nms.reset(new NmsWorkspace(4096, net->batch_max));
+        for (int k = 0; k < 2; ++k) {
+            for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
+            nms[k].reset(new NmsWorkspace(4096, net->batch_max));
+        }
     }
     ~Pipeline() {
-        for (hipEvent_t e : {e0, e1, e2, e_nms}) (void)hipEventDestroy(e);
+        for (int k = 0; k < 2; ++k)
+            for (hipEvent_t e : {e0[k], e1[k], e2[k], e_nms[k]}) (void)hipEventDestroy(e);
     }
 
+    // One detector pass over a batch AND its NMS, all asynchronous on the detector stream.  Two NMS workspaces (and
+    // their pinned result buffers) alternate, so that the pass of batch i+1 can be enqueued before the host has waited
+    // for and read the results of batch i: the detector stream never drains between passes.
     void launch_detector(const uint8_t *frames_dev, int h, int w, int batch) {
-        YDS_HIP(hipEventRecord(e0, net->stream));
+        const int k = (in_flight_slot ^= 1);
+        YDS_HIP(hipEventRecord(e0[k], net->stream));
         launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream);
-        YDS_HIP(hipEventRecord(e1, net->stream));
+        YDS_HIP(hipEventRecord(e1[k], net->stream));
         net->forward_resized(batch);
-        YDS_HIP(hipEventRecord(e2, net->stream));
+        YDS_HIP(hipEventRecord(e2[k], net->stream));
+        const float sx = (float)((double)w / net->img_w), sy = (float)((double)h / net->img_h);
+        nms[k]->launch(net->out.p, (size_t)net->total_boxes * net->attrs, batch, net->total_boxes, net->attrs, conf, nms_thres, sx, sy, 300,
+                       net->stream);
+        YDS_HIP(hipEventRecord(e_nms[k], net->stream));
         in_flight = frames_dev;
         in_flight_batch = batch;
     }
@@ -51,20 +62,20 @@ public:
         bool reid_in_flight = false;
     };
 
-    // wait for the detector pass in flight, run NMS for all its frames, build the detection lists
-    void finish_detector(Dets &d, const uint8_t *frames_dev, int h, int w, int batch) {
-        const float sx = (float)((double)w / net->img_w), sy = (float)((double)h / net->img_h);
-        nms->launch(net->out.p, (size_t)net->total_boxes * net->attrs, batch, net->total_boxes, net->attrs, conf, nms_thres, sx, sy, 300,
-                    net->stream);
-        YDS_HIP(hipEventRecord(e_nms, net->stream));
-        YDS_HIP(hipEventSynchronize(e_nms));
-        in_flight = nullptr;
+    // wait for the detector pass + NMS enqueued in slot k, build the detection lists
+    void finish_detector(Dets &d, int k, const uint8_t *frames_dev, int batch) {
+        YDS_HIP(hipEventSynchronize(e_nms[k]));
+        float ms01 = 0, ms12 = 0;
+        YDS_HIP(hipEventElapsedTime(&ms01, e0[k], e1[k]));
+        YDS_HIP(hipEventElapsedTime(&ms12, e1[k], e2[k]));
+        stage_us[0] = ms01 * 1e3f; stage_us[1] = ms12 * 1e3f;
+        NmsWorkspace *nmsw = nms[k].get();
         std::vector<float> det(300 * 6);
         d.tlwh.clear(); d.payload.clear(); d.frame_of.clear();
         d.first.assign(batch + 1, 0); d.n_det.assign(batch, 0);
         d.frames = frames_dev; d.batch = batch; d.reid_in_flight = false;
         for (int b = 0; b < batch; ++b) {
-            d.n_det[b] = nms->collect(b, det.data(), 300);
+            d.n_det[b] = nmsw->collect(b, det.data(), 300);
             for (int i = 0; i < d.n_det[b]; ++i) {
                 const float *r = &det[i * 6];
                 bool keep = class_mask.empty();
@@ -91,24 +102,27 @@ public:
         auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
         if (batch < 1 || batch > net->batch_max) fail("pipeline: batch %d outside [1,%d]", batch, net->batch_max);
         auto t_begin = clk::now();
-        float ms01 = 0, ms12 = 0;
         const bool resumed = ahead.reid_in_flight && ahead.frames == frames_dev && ahead.batch == batch;
+        int next_slot = -1;
+        auto launch_next = [&]() {                                  // detector (+ NMS) of the next batch goes in flight
+            if (!next_frames_dev) return;
+            if (next_inject_set >= 0) net->select_injection_set(next_inject_set);      // bench-only logit injection
+            launch_detector(next_frames_dev, h, w, batch);
+            next_slot = in_flight_slot;
+        };
         if (resumed) {
             std::swap(cur, ahead);                                  // NMS done and ReID already running since the previous call
             ahead.reid_in_flight = false;
+            launch_next();
         } else {
             ahead.reid_in_flight = false;
             if (in_flight != frames_dev || in_flight_batch != batch) launch_detector(frames_dev, h, w, batch);
-            finish_detector(cur, frames_dev, h, w, batch);
-            YDS_HIP(hipEventElapsedTime(&ms01, e0, e1));
-            YDS_HIP(hipEventElapsedTime(&ms12, e1, e2));
+            const int slot = in_flight_slot;
+            in_flight = nullptr;
+            launch_next();                                          // enqueued BEFORE the host waits for this batch's NMS
+            finish_detector(cur, slot, frames_dev, batch);
         }
         auto t_nms = clk::now();
-        // detector of the next batch goes in flight now: it overwrites `out` only after the NMS kernels of this batch
-        if (next_frames_dev) {
-            if (next_inject_set >= 0) net->select_injection_set(next_inject_set);      // bench-only logit injection
-            launch_detector(next_frames_dev, h, w, batch);
-        }
         if (!resumed) launch_reid(cur, h, w);
         const int D_all = (int)cur.payload.size();
         if (D_all) {
@@ -123,9 +137,8 @@ public:
         // cores stay busy underneath.  Sparse scenes keep the simpler order (the detector alone covers the association).
         const int deep_min = getenv("YDS_PIPE_DEEP_MIN") ? atoi(getenv("YDS_PIPE_DEEP_MIN")) : 64;    // detections per frame
         if (next_frames_dev && D_all >= deep_min * batch) {
-            finish_detector(ahead, next_frames_dev, h, w, batch);
-            YDS_HIP(hipEventElapsedTime(&ms01, e0, e1));
-            YDS_HIP(hipEventElapsedTime(&ms12, e1, e2));
+            finish_detector(ahead, next_slot, next_frames_dev, batch);
+            in_flight = nullptr;
             launch_reid(ahead, h, w);
         }
         for (int b = 0; b < batch; ++b) {
@@ -135,7 +148,6 @@ public:
                                   cur.payload.data() + cur.first[b], D, out6 + (size_t)b * cap * 6, cap);
         }
         auto t_end = clk::now();
-        if (ms12 > 0) { stage_us[0] = ms01 * 1e3f; stage_us[1] = ms12 * 1e3f; }
         stage_us[2] = us(t_begin, t_nms); stage_us[3] = us(t_nms, t_reid); stage_us[4] = us(t_reid, t_end);
     }
 
@@ -144,13 +156,14 @@ public:
     TrackerIface *trk;
     float conf, nms_thres;
     std::vector<int32_t> class_mask;
-    std::unique_ptr<NmsWorkspace> nms;
+    std::unique_ptr<NmsWorkspace> nms[2];
+    int in_flight_slot = 0;
     Dets cur, ahead;                // this batch; the next batch when its ReID pass was started early
     DevBuf<float> feat_cur;
     int next_inject_set = -1;      // bench-only: injection set of the prefetched detector pass
     const uint8_t *in_flight = nullptr;
     int in_flight_batch = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e_nms = nullptr;
+    hipEvent_t e0[2] = {}, e1[2] = {}, e2[2] = {}, e_nms[2] = {};
     float stage_us[5] = {0, 0, 0, 0, 0};
 };
 
