@@ -336,7 +336,14 @@ static std::map<std::string, int> &tune_cache() {
 }
 static std::string tune_key(const ConvArgs &a) {
     char buf[256];
-    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d", conv_math(), a.x.n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
+    // image counts above 64 (ReID crop batches, which vary from call to call) are keyed by a coarse bucket: 2^k or 1.5 * 2^k
+    int n = a.x.n;
+    if (n > 64) {
+        int p2 = 64;
+        while (p2 * 2 <= n) p2 *= 2;
+        n = n >= p2 + p2 / 2 ? p2 + p2 / 2 : p2;
+    }
+    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d", conv_math(), n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
              a.y.h, a.y.w, a.ksize, a.stride, a.act, a.res.p ? a.res_mode : 0, a.x.fmt, a.y.fmt);
     return buf;
 }
