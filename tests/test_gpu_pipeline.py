@@ -67,3 +67,43 @@ def test_pipeline_matches_oracle_stream(name, size, batch, deep, monkeypatch):
     assert got[5] is None and seen_rows > 5 * 8
     st = pipe.stage_us()
     assert st["detector_dev"] > 0
+
+
+def test_video_detector_batched_lookahead_equals_frame_by_frame():
+    """VideoDetector(batch_frames=N) reads N frames ahead and runs the batched pipeline; per-frame results must be the
+    ones of the reference-style frame-by-frame loop (ids / classes bit exact, boxes within a pixel)."""
+    import os
+    import tempfile
+    from yolo_deepsort_amd import _lib
+    from yolo_deepsort_amd.deep_sort import DeepSort
+    from yolo_deepsort_amd.detect import VideoDetector
+    from yolo_deepsort_amd.models import Darknet
+    _lib.init(0)
+    cfg = cfgs.cfg_text("yolov3-tiny", 416, 416)
+    blob = synth.darknet_weights_blob(cfg, 0, -1.45)          # a handful of (random) detections per frame
+    sd = synth.reid_state_dict(0)
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+    rng = np.random.RandomState(21)
+    base = rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    frames = [np.roll(base, 3 * t, axis=1) for t in range(11)]
+    runs = {}
+    for bf in (1, 4):
+        net = Darknet(None, img_size=(416, 416), batch_max=max(bf, 1), cfg_text=cfg)
+        net.load_darknet_weights(None, blob=blob)
+        vd = VideoDetector(net, f.name, thres=0.5, nms_thres=0.4, skip_frames=2, tracker=DeepSort(sd, use_cuda=True, **DS),
+                           batch_frames=bf)
+        runs[bf] = [(img.shape, None if d is None else np.array(d, np.int32).reshape(-1, 6)) for img, d, _ in vd.detect(frames)]
+    os.unlink(f.name)
+    assert len(runs[1]) == len(runs[4]) == len(frames)
+    rows = 0
+    for t, ((s1, d1), (s4, d4)) in enumerate(zip(runs[1], runs[4])):
+        assert s1 == s4 == (480, 640, 3)
+        assert (d1 is None) == (d4 is None), t
+        if d1 is None:
+            continue
+        assert d1.shape == d4.shape, t
+        assert np.array_equal(d1[:, 4:], d4[:, 4:]), t
+        assert np.abs(d1[:, :4] - d4[:, :4]).max(initial=0) <= 1, t
+        rows += len(d1)
+    assert rows > 0
