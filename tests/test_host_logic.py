@@ -184,3 +184,23 @@ def test_save_darknet_weights_layout_roundtrip():
         assert len(part) == 20 + used * 4 and part[20:] == blob[20:20 + used * 4]
     finally:
         os.unlink(f.name)
+
+
+def test_resize_restatement_geometry_vs_torch_interpolate():
+    """cv2 is absent, so the bilinear resize is 'parity unpinned' (oracle/resize.py).  Its GEOMETRY (half-pixel centres,
+    edge clamping, weights) is at least cross-checked against an independent implementation that IS in the image:
+    torch's bilinear interpolate (align_corners=False) on the same uint8 data, compared before rounding -> the rounded
+    results may differ by one grey level at most, and only where the unrounded value sits next to a .5 tie (the
+    restatement computes sample coordinates in fp32 like the device kernel, torch in fp64)."""
+    import torch
+    from oracle.resize import resize_bilinear_u8
+    rng = np.random.RandomState(9)
+    for (h, w), (dh, dw) in (((480, 640), (416, 416)), ((1080, 1920), (608, 608)), ((37, 91), (128, 64)), ((300, 200), (128, 64))):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        got = resize_bilinear_u8(img, (dw, dh)).astype(np.int32)
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].double()
+        ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        diff = np.abs(got - ref)
+        assert diff.max() <= 0.5 + 0.02, ((h, w), float(diff.max()))
+        assert (got != np.rint(ref)).mean() < 1e-2, ((h, w), float((got != np.rint(ref)).mean()))
+        assert got.shape == (dh, dw, 3)
