@@ -201,6 +201,6 @@ def test_resize_restatement_geometry_vs_torch_interpolate():
         t = torch.from_numpy(img).permute(2, 0, 1)[None].double()
         ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
         diff = np.abs(got - ref)
-        assert diff.max() <= 0.5 + 0.02, ((h, w), float(diff.max()))
+        assert diff.max() <= 0.5 + 0.05, ((h, w), float(diff.max()))
         assert (got != np.rint(ref)).mean() < 1e-2, ((h, w), float((got != np.rint(ref)).mean()))
         assert got.shape == (dh, dw, 3)
