@@ -12,7 +12,7 @@ frames=np.random.RandomState(0).randint(0,256,(B,1080,1920,3)).astype(np.uint8)
 dev=_lib.DeviceBuffer.from_array(frames)
 for i in range(3): _lib.check(lib.yds_darknet_forward_u8_dev(net._h, dev.offset(0), 1080,1920,B))
 _lib.check(lib.yds_device_sync())
-t=time.perf_counter(); N=30
+t=time.perf_counter(); N=int(os.environ.get("DET_LOOP_N", "30"))
 for i in range(N): _lib.check(lib.yds_darknet_forward_u8_dev(net._h, dev.offset(0), 1080,1920,B))
 _lib.check(lib.yds_device_sync())
 dt=(time.perf_counter()-t)/N
