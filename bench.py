@@ -28,6 +28,7 @@ CONFIGS = {
     "cfg5": dict(net="yolov4", persons=200, visible=150, workload="yolov4.cfg 608x608 + DeepSORT, crowd stream 200 tracks / 150 detections per frame"),
 }
 DS_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)   # video_deepsort.py:18-25
+MEASURED_F16_MFMA_TFLOPS = 1824.0      # tools/probes/mfma_probe, random operands, 1.3 s launch at the power limit
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-in MFMA = 64 FLOP/clk/SIMD
 PEAK_F16_MFMA_TFLOPS = 2500.0         # dense fp16/bf16 MFMA (not the 2:1-sparse headline)
 
@@ -158,6 +159,8 @@ def main():
                             peak_note=("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16
                                        else "fp32-input MFMA, 64 FLOP/clk/SIMD"),
                             frac_of_fp32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                            # pure-MFMA loop on random fp16 data, sustained (power limited): profiles/r01_ablation_dma.txt #6
+                            frac_of_measured_mfma_ceiling=round(achieved / (MEASURED_F16_MFMA_TFLOPS / 3 if f16 else PEAK_F32_MFMA_TFLOPS), 4),
                             avg_launch_us=round(avg_us, 2), launches=int(dom["launches"]),
                             flops_per_launch=dom["flops"] / dom["launches"])
             # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from

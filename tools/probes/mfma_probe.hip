@@ -11,10 +11,15 @@ constexpr int ROWB = 144;
 // MODE 2: + s_barrier per step
 // MODE 3: MODE 2 with fragment reads of step k+1 issued before the MFMAs of step k (software pipelining)
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void probe(float *out, int steps) {
+__global__ __launch_bounds__(256, 2) void probe(float *out, int steps, int random_data) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 2 * 256 * ROWB / 4; i += 256) reinterpret_cast<float *>(lds)[i] = 0.001f * (i & 15);
+    // operand data: near-constant values (low switching activity) or pseudo-random fp16 bit patterns (realistic power)
+    for (int i = tid; i < 2 * 256 * ROWB / 4; i += 256) {
+        unsigned h = (unsigned)(i + 977 * blockIdx.x) * 2654435761u;
+        unsigned bits = ((h >> 3) & 0x03ff03ffu) | 0x38003800u | (h & 0x80008000u);       // two fp16 in [0.5, 1), random signs
+        if (random_data) reinterpret_cast<unsigned *>(lds)[i] = bits; else reinterpret_cast<float *>(lds)[i] = 0.001f * (i & 15);
+    }
     __syncthreads();
     f32x16 acc1[2][2], acc2[2][2];
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0; acc2[i][j][e] = 0; }
@@ -60,29 +65,33 @@ __global__ __launch_bounds__(256, 2) void probe(float *out, int steps) {
     if (s == 123.456f) out[0] = s;
 }
 
-template <int MODE> void run(const char *name, int wg_per_cu) {
+template <int MODE> void run(const char *name, int wg_per_cu, int random_data, int steps = 2000) {
     float *o; hipMalloc(&o, 4);
-    const int steps = 2000, grid = 256 * wg_per_cu;
+    const int grid = 256 * wg_per_cu;
     size_t smem = 2 * 256 * ROWB;
     hipFuncSetAttribute(reinterpret_cast<const void *>(probe<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9;
     for (int r = 0; r < 4; ++r) {
         hipEventRecord(e0);
-        probe<MODE><<<grid, 256, smem>>>(o, steps);
+        probe<MODE><<<grid, 256, smem>>>(o, steps, random_data);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
     double flops = (double)grid * 4 * steps * 24 * 32768.0;
-    printf("%-44s %d WG/CU: %8.1f us  %7.1f TFLOP/s MFMA  (%.1f fp32-equivalent)\n", name, wg_per_cu, best * 1e3, flops / best / 1e9, flops / best / 1e9 / 3);
+    printf("%-44s %d WG/CU %s data: %9.1f us  %7.1f TFLOP/s MFMA  (%.1f fp32-equivalent)\n", name, wg_per_cu, random_data ? "random" : "flat  ", best * 1e3,
+           flops / best / 1e9, flops / best / 1e9 / 3);
     hipFree(o);
 }
 int main() {
-    for (int w : {1, 2}) {
-        run<0>("mfma only", w);
-        run<1>("mfma + 16 ds_read_b128 / step", w);
-        run<2>("mfma + ds_read + barrier", w);
-        run<3>("software-pipelined reads + barrier", w);
-    }
+    for (int rnd : {0, 1})
+        for (int w : {1, 2}) {
+            run<0>("mfma only", w, rnd);
+            run<1>("mfma + 16 ds_read_b128 / step", w, rnd);
+            run<2>("mfma + ds_read + barrier", w, rnd);
+            run<3>("software-pipelined reads + barrier", w, rnd);
+        }
+    // sustained: ~1 s of back-to-back MFMAs on random data (power limit / clock state)
+    run<0>("mfma only, 0.6 s launches", 2, 1, 1500000);
     return 0;
 }
