@@ -227,6 +227,9 @@ def test_reid_larger_batch_vs_oracle():
     ex = Extractor(sd, max_crops=64)
     x = np.random.RandomState(2).randn(37, 3, 128, 64).astype(F32)
     np.testing.assert_allclose(ex.forward(x), oreid.reid_forward(x, sd), rtol=RTOL, atol=1e-5)
+    # one and three crops: the last stages have fewer rows (8x4 = 32 per crop) than one 256-row tile
+    for d in (1, 3):
+        np.testing.assert_allclose(ex.forward(x[:d]), oreid.reid_forward(x[:d], sd), rtol=RTOL, atol=1e-5)
 
 
 # ----------------------------------------------------------------------------------------- Kalman
