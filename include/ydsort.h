@@ -69,6 +69,10 @@ int yds_darknet_forward_f32(yds_net *, const float *nchw_host, int batch, float 
 int yds_darknet_forward_u8(yds_net *, const uint8_t *rgb_hwc_host, int h, int w, int batch,
                            float *out_host_or_null);
 int yds_darknet_forward_u8_dev(yds_net *, const uint8_t *rgb_hwc_dev, int h, int w, int batch);
+/* device copy of the frames the last yds_darknet_forward_u8 call uploaded (valid until the next one; NULL if none):
+ * lets DeepSort.update crop from it instead of uploading the same frame again (video_detect.py:134-149 hands the same
+ * frame to the detector and to the tracker) */
+const uint8_t *yds_darknet_last_frames_dev(yds_net *, int *h, int *w, int *batch);
 int yds_darknet_layer_output(yds_net *, int layer, int batch, float *nchw_host);   /* parity tests */
 int yds_darknet_get_input(yds_net *, int batch, float *nchw_host);                 /* parity tests */
 /* bench-only: overwrite head logits so the decode yields scripted boxes.

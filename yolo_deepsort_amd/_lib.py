@@ -48,6 +48,7 @@ SIGNATURES = {
     "yds_darknet_forward_f32": (_I, [_P, _P, _I, _P]),
     "yds_darknet_forward_u8": (_I, [_P, _P, _I, _I, _I, _P]),
     "yds_darknet_forward_u8_dev": (_I, [_P, _P, _I, _I, _I]),
+    "yds_darknet_last_frames_dev": (_P, [_P, _P, _P, _P]),
     "yds_darknet_layer_output": (_I, [_P, _I, _I, _P]),
     "yds_darknet_get_input": (_I, [_P, _I, _P]),
     "yds_darknet_set_injection": (_I, [_P, _I, _P, _I, _F]),

@@ -498,6 +498,7 @@ void Darknet::forward_u8_host(const uint8_t *frames, int h, int w, int batch, fl
     size_t n = (size_t)batch * h * w * 3;
     stage_u8.ensure(n);
     YDS_HIP(hipMemcpyAsync(stage_u8.p, frames, n, hipMemcpyHostToDevice, stream));
+    stage_h = h; stage_w = w; stage_n = batch;
     forward_u8_dev(stage_u8.p, h, w, batch);
     if (out_host) YDS_HIP(hipMemcpyAsync(out_host, out.p, (size_t)batch * total_boxes * attrs * sizeof(float), hipMemcpyDeviceToHost, stream));
     YDS_HIP(hipStreamSynchronize(stream));
@@ -639,6 +640,11 @@ int yds_darknet_forward_u8(yds_net *n, const uint8_t *rgb, int h, int w, int bat
     YDS_API_BEGIN
     n->d->forward_u8_host(rgb, h, w, batch, out_host);
     YDS_API_END
+}
+const uint8_t *yds_darknet_last_frames_dev(yds_net *n, int *h, int *w, int *batch) {
+    if (!n || !n->d->stage_n) return nullptr;
+    *h = n->d->stage_h; *w = n->d->stage_w; *batch = n->d->stage_n;
+    return n->d->stage_u8.p;
 }
 int yds_darknet_forward_u8_dev(yds_net *n, const uint8_t *rgb_dev, int h, int w, int batch) {
     YDS_API_BEGIN

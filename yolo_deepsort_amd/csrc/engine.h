@@ -80,6 +80,7 @@ public:
     std::vector<int> yolo_layers;
     DevBuf<float> input, out, stage_f32;
     DevBuf<uint8_t> stage_u8;
+    int stage_h = 0, stage_w = 0, stage_n = 0;               // frames last uploaded by forward_u8_host (device copy in stage_u8)
     DevBuf<float> tiled_pred, tile_scale;
     DevBuf<int> tile_rects;
     hipStream_t stream = nullptr;

@@ -45,12 +45,15 @@ class Extractor:
             print("Loading weights from {}... Done!".format(model_path))
 
     # frame + boxes entry (what DeepSort uses)
-    def embed(self, frame, tlwh, to_host=True):
-        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    def embed(self, frame, tlwh, to_host=True, frame_dev=None):
+        """frame_dev: device copy of `frame` (the detector's upload) - skips a second host-to-device copy of the frame."""
         tlwh = _np(tlwh).reshape(-1, 4)
         d = tlwh.shape[0]
         out = np.empty((d, 512), np.float32) if to_host else None
-        if d:
+        if d and frame_dev is not None:
+            _lib.check(_lib.load().yds_reid_embed_dev(self._h, frame_dev, frame.shape[0], frame.shape[1], _lib.ptr(tlwh), d, _lib.ptr(out)))
+        elif d:
+            frame = np.ascontiguousarray(frame, dtype=np.uint8)
             _lib.check(_lib.load().yds_reid_embed(self._h, _lib.ptr(frame), frame.shape[0], frame.shape[1],
                                                   _lib.ptr(tlwh), d, _lib.ptr(out)))
         return out
@@ -211,7 +214,9 @@ class DeepSort(object):
         tlwh = _np(bbox_xywh).reshape(-1, 4)
         d = tlwh.shape[0]
         if isinstance(self.extractor, Extractor):
-            self.extractor.embed(ori_img, tlwh, to_host=False)
+            hint, self.frame_source = getattr(self, "frame_source", None), None
+            frame_dev = hint.last_frame_dev(ori_img) if hint is not None else None      # the detector already uploaded this frame
+            self.extractor.embed(ori_img, tlwh, to_host=False, frame_dev=frame_dev)
             rows = self.tracker.step(tlwh, None, payload, feats_dev=self.extractor.features_dev())
         else:                                          # user-supplied extractor callable (reference allows it)
             crops = []

@@ -128,6 +128,8 @@ class VideoDetector:
             if self.class_mask is not None:
                 mask = reduce(lambda a, b: a | b, [class_ids == m for m in self.class_mask])
                 boxs, confidences, class_ids = boxs[mask], confidences[mask], class_ids[mask]
+            if hasattr(self.tracker, "extractor"):
+                self.tracker.frame_source = self.image_detector.model       # lets update() crop from the detector's device copy
             detections = self.tracker.update(boxs.astype(np.float32), confidences, frame, class_ids)
         return detections
 

@@ -134,6 +134,7 @@ class Darknet:
     # -- engine extras ---------------------------------------------------
     def forward_u8(self, frames, want_output=True):
         """frames uint8 [B,H,W,3] (host) -> decoded predictions [B,N,5+C]."""
+        self._last_frame_src = frames                      # identity of what was uploaded (see last_frame_dev)
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
         if frames.ndim == 3:
             frames = frames[None]
@@ -143,6 +144,16 @@ class Darknet:
         out = np.empty((b, self.num_boxes, self.num_attrs), np.float32) if want_output else None
         _lib.check(_lib.load().yds_darknet_forward_u8(self._h, _lib.ptr(frames), h, w, b, _lib.ptr(out)))
         return out
+
+    def last_frame_dev(self, frame):
+        """Device pointer of `frame` if it is the single frame the last forward_u8 uploaded, else None."""
+        if getattr(self, "_last_frame_src", None) is not frame:
+            return None
+        h, w, b = C.c_int(), C.c_int(), C.c_int()
+        p = _lib.load().yds_darknet_last_frames_dev(self._h, C.byref(h), C.byref(w), C.byref(b))
+        if not p or b.value != 1 or (h.value, w.value) != tuple(frame.shape[:2]):
+            return None
+        return C.c_void_p(p)
 
     def nms(self, image, conf_thres, iou_thres, frame_hw=None, cap=300):
         """soft_non_max_suppression (+ resize_boxes when frame_hw is given) on the last forward."""
