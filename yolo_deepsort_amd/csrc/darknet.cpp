@@ -466,6 +466,9 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
             View head = view(l.src, batch);
             int hidx = 0;
             for (int y : yolo_layers) { if (y == i) break; ++hidx; }
+            // `out` is about to be overwritten: wait for whoever still reads the previous pass's predictions (pipeline NMS
+            // running on its own stream); the first decode sits ~3/4 into the pass, so this wait is free in practice
+            if (hidx == 0 && out_guard) YDS_HIP(hipStreamWaitEvent(stream, out_guard, 0));
             if (inject_active && inject_set >= 0) {
                 launch_inject_batch(head, batch, inject_table.p, inject_offsets_dev.p + (size_t)inject_set * batch_max + first, inject_max_rows, hidx,
                                     l.classes, inject_logit, stream);

@@ -106,6 +106,7 @@ public:
 private:
     void run_graph(int batch);
     void run_lane(int first, int batch, hipStream_t st);      // layers over images [first, first + batch) on one stream
+    hipEvent_t out_guard = nullptr;                           // optional: event the decode waits for before it overwrites `out`
     int lane_img0 = 0;                                        // image offset applied by view() / input_view() while a lane is enqueued
     std::vector<hipStream_t> lane_streams;
     std::vector<hipEvent_t> lane_done;

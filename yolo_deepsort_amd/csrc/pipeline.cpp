@@ -29,10 +29,12 @@ public:
             for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
             nms[k].reset(new NmsWorkspace(4096, net->batch_max));
         }
+        YDS_HIP(hipStreamCreateWithFlags(&nms_stream, hipStreamNonBlocking));
     }
     ~Pipeline() {
         for (int k = 0; k < 2; ++k)
             for (hipEvent_t e : {e0[k], e1[k], e2[k], e_nms[k]}) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(nms_stream);
     }
 
     // One detector pass over a batch AND its NMS, all asynchronous on the detector stream.  Two NMS workspaces (and
@@ -157,6 +159,7 @@ public:
     float conf, nms_thres;
     std::vector<int32_t> class_mask;
     std::unique_ptr<NmsWorkspace> nms[2];
+    hipStream_t nms_stream = nullptr;
     int in_flight_slot = 0;
     Dets cur, ahead;                // this batch; the next batch when its ReID pass was started early
     DevBuf<float> feat_cur;
