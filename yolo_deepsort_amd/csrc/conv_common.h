@@ -86,8 +86,13 @@ inline int plan_tile_map(ConvKernelArgs &k, int BM, int BN) {
 // and row contiguous: bias, residual and output move as float4 along the channel axis.  One pass per row of waves
 // keeps the staging area at (BM/WM) x (BN+4) floats, which fits inside every variant's main-loop allocation.
 // ACT / RES are compile-time.
-template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256>
-__device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
+// RowMap: tile row -> flat output pixel index (or < 0 for "no such pixel"); FlatRows = consecutive pixels from m0
+struct FlatRows {
+    int m0;
+    __device__ __forceinline__ int operator()(int row) const { return m0 + row; }
+};
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, class RowMap = FlatRows>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, RowMap rows, int n0, int tid) {
     constexpr int ROWS = BM / WM, LD = BN + 4, C4 = BN / 4;        // staged rows, padded row length, float4 per row
     constexpr int RSTEP = NT / C4;                                   // rows covered by one sweep of the NT threads
     static_assert(NT % C4 == 0 && C4 % 2 == 0 && ROWS % RSTEP == 0, "tile width must divide the workgroup; lane pairs share a row");
@@ -117,8 +122,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&
         __syncthreads();
 #pragma unroll
         for (int r = rr; r < ROWS; r += RSTEP) {
-            const int m = m0 + pass * ROWS + r;
-            const bool live = m < p.M && n < p.Cout;             // no early exit: lane pairs trade halves below
+            const int m = rows(pass * ROWS + r);
+            const bool live = m >= 0 && m < p.M && n < p.Cout;   // no early exit: lane pairs trade halves below
             float4 v = *reinterpret_cast<const float4 *>(stage + r * LD + c4 * 4);
             float rs[4] = {0.f, 0.f, 0.f, 0.f};
             if (RES != RES_NONE && live) {
@@ -160,7 +165,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&
     }
 }
 
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256>
+__device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
+    conv_epilogue_rows<BM, BN, WM, WN, ACT, RES, TM, TN, NT, FlatRows>(p, acc, stage, FlatRows{m0}, n0, tid);
+}
+
 ConvKernelArgs make_conv_args(const ConvArgs &a);
+// fused detector stem (conv_stem2.hip): 3x3/s1 RGB conv (direct, vector ALU) + 3x3/s2 32->64 conv (f16x3 MFMA) in one kernel
+bool conv_stem2_applicable(const ConvKernelArgs &k0, const ConvKernelArgs &k1);
+void launch_conv_stem2(const ConvKernelArgs &k0, const ConvKernelArgs &k1, hipStream_t s);
 
 // dispatch on (activation, residual mode) to the compile-time epilogue instantiation of launcher L<ACT, RES>
 #define YDS_DISPATCH_ACT_RES(k, CALL)                                                                     \

@@ -184,6 +184,9 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
             l.coff = 0;
         }
     }
+    // the first two convolutions can run as one kernel (conv_stem2.hip) when only layer 1 reads layer 0
+    stem_fusable = L >= 2 && layers[0].type == "convolutional" && layers[1].type == "convolutional" && readers[0] == 1 &&
+                   layers[1].src == 0 && layers[0].fused_res < 0 && layers[1].fused_res < 0;
     // single-source routes are views
     for (int i = 0; i < L; ++i) {
         Layer &l = layers[i];
@@ -436,8 +439,19 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
         if (l.type == "convolutional") {
             if (!l.loaded) fail("forward: layer %d has no weights (call load_darknet_weights)", i);
             ConvArgs a = conv_args(i, batch);
+            if (i == 0 && stem_fused(batch)) continue;              // computed inside layer 1's launch
             if (time_convs) YDS_HIP(hipEventRecord(ev0, stream));
-            int variant = launch_conv(a, stream, l.variant);
+            int variant;
+            if (i == 1 && stem_fused(batch)) {
+                ConvArgs a0 = conv_args(0, batch);
+                ConvKernelArgs k0 = make_conv_args(a0), k1 = make_conv_args(a);
+                k1.w = reinterpret_cast<const float *>(a.w16);
+                launch_conv_stem2(k0, k1, stream);
+                variant = kDirectVariant;                           // accounted with the direct first-layer kernel
+                if (time_convs) conv_flops_acc[variant] += conv_flops(a0);
+            } else {
+                variant = launch_conv(a, stream, l.variant);
+            }
             if (time_convs) {
                 YDS_HIP(hipEventRecord(ev1, stream));
                 YDS_HIP(hipEventSynchronize(ev1));
@@ -535,9 +549,24 @@ void Darknet::forward_tiles_host(const uint8_t *frame, int h, int w, const int *
     YDS_HIP(hipStreamSynchronize(stream));          // `scale` and the caller's buffers may go away
 }
 
+bool Darknet::stem_fused(int batch) {
+    static const bool off = getenv("YDS_NO_STEM_FUSE") != nullptr;
+    if (off || !stem_fusable || conv_math() != MATH_F16X3 || !layers[0].loaded || !layers[1].loaded) return false;
+    if (stem_checked != batch) {
+        ConvArgs a0 = conv_args(0, batch), a1 = conv_args(1, batch);
+        stem_ok = a1.w16 && a1.y.fmt == FMT_H16 && conv_stem2_applicable(make_conv_args(a0), make_conv_args(a1));
+        stem_checked = batch;
+    }
+    return stem_ok;
+}
+
 void Darknet::layer_output_host(int i, int batch, float *nchw) {
     if (i < 0 || i >= (int)layers.size()) fail("layer_output: no layer %d", i);
     const Layer &l = layers[i];
+    if (i == 0 && stem_fused(batch)) {                            // the fused stem never writes layer 0: produce it on demand
+        ConvArgs a0 = conv_args(0, batch);
+        (void)launch_conv(a0, stream, layers[0].variant);
+    }
     if (l.type == "yolo") fail("layer_output: yolo layers are read through the forward output");
     if (l.fused_res >= 0) fail("layer_output: layer %d is fused with the following shortcut", i);
     View v = view(i, batch);

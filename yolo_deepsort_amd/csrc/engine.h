@@ -106,6 +106,9 @@ public:
 private:
     void run_graph(int batch);
     void run_lane(int first, int batch, hipStream_t st);      // layers over images [first, first + batch) on one stream
+    bool stem_fusable = false, stem_ok = false;               // layers 0+1 as one kernel (conv_stem2.hip)
+    int stem_checked = -1;
+    bool stem_fused(int batch);
     hipEvent_t out_guard = nullptr;                           // optional: event the decode waits for before it overwrites `out`
     int lane_img0 = 0;                                        // image offset applied by view() / input_view() while a lane is enqueued
     std::vector<hipStream_t> lane_streams;
