@@ -1,6 +1,6 @@
 """Detector-only loop (resize + all layers + decode, frames resident in HBM): tools/det_loop.py  (run on the GPU box)"""
 import sys, time, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ctypes as C
 from yolo_deepsort_amd import _lib, cfgs, synth
 from yolo_deepsort_amd.models import Darknet

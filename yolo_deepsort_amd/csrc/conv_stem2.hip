@@ -5,9 +5,12 @@
 // Unfused, layer 0 writes 608*608*32 values per image (757 MB per 16 frames) that layer 1 reads straight back: the two
 // launches are HBM bound on that tensor (322 + 349 us per 16 frames, ~340 us of it for the round trip).  Here a 512-thread
 // persistent workgroup owns an 8 x 16 patch of LAYER-1 outputs:
-//   phase A  the 17 x 33 layer-0 pixels it needs are computed on the vector ALU from an RGB tile in LDS (the fma chain and
-//            register-resident weights of conv_first.hip: 8 lanes per pixel, 4 channels each) and written to LDS as pre-split
-//            H16 rows (128 B = [32 hi | 32 lo] fp16 per pixel); pixels outside the image are written as zeros (layer 1 pads)
+//   phase A  the 17 x 33 layer-0 pixels it needs are computed as an f16x3 MFMA product too (K = 9 taps x 4 = 36 -> 48): the
+//            filter fragments (32 x 48, split on the fly) live in registers, the pixel fragments are gathered from a split
+//            RGB tile in LDS ([hi r g b 0 | lo r g b 0] per pixel, two 8-byte reads per 8 k), operands swapped so that a lane
+//            ends up with 4 consecutive channels of ONE pixel, which go to LDS as pre-split H16 rows (128 B = [32 hi | 32 lo]
+//            fp16 per pixel, 8-byte writes); pixels outside the image are written as zeros (layer 1 pads).  (A vector-ALU
+//            version of this phase cost 255 of 451 us: 27-deep fma chains at two waves per SIMD.)
 //   phase B  layer 1 as 9 taps x 2 k-substeps of f16x3 MFMAs (3 per 32x32 tile and substep) straight from that LDS patch;
 //            the 64 x 288 filter matrix (74 KB pre-split) is loaded into LDS once per workgroup
 //   epilogue shared conv_epilogue (bias, activation, H16 encode, 16-byte stores) with a patch row map
@@ -18,6 +21,10 @@
 #include "conv_common.h"
 
 #include <algorithm>
+
+#ifndef YDS_STEM_ABL
+#define YDS_STEM_ABL 0     // experiment builds: 1 no phase A (layer 0), 2 no phase B (MFMAs), 3 no epilogue
+#endif
 
 namespace yds {
 
@@ -61,69 +68,103 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
         const f32x4 v = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p1.w) + ((size_t)min(co, p1.Cout - 1) * 9 + tap) * 128 + c * 16);
         *reinterpret_cast<f32x4 *>(wreg + row * 128 + pos * 16) = v;
     }
-    // layer-0 weights of this lane: 4 output channels x 9 taps x 3 input channels (+ bias), as channel pairs (v_pk_fma_f32)
-    const int q = tid & 7, slot = tid >> 3;
-    f32x2 w0[2][9][3], b0[2];
+    // layer-0 filter fragments (first MFMA operand: row = output channel lane & 31, k = 16 s + 8 kb + 0..7 = taps 4s + 2kb,
+    // 4s + 2kb + 1 x (r, g, b, pad)), split hi / lo on the fly, and the biases of the 16 channels this lane's accumulators hold
+    const int kb0 = lane >> 5;
+    h8 w0h[3], w0l[3];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        const float *wr = p0.w + (size_t)(q * 4 + o) * p0.Kpad;
-        b0[o / 2][o % 2] = p0.bias[q * 4 + o];
+    for (int sb = 0; sb < 3; ++sb)
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int e = 0; e < 8; ++e) {
+            const int t = 4 * sb + 2 * kb0 + (e >> 2), c = e & 3;
+            const float x = (t < 9 && c < 3) ? p0.w[(size_t)(lane & 31) * p0.Kpad + t * 4 + c] : 0.f;
+            const _Float16 h = (_Float16)x;
+            w0h[sb][e] = h;
+            w0l[sb][e] = (_Float16)((x - (float)h) * LO_SCALE);
+        }
+    float bias0[16];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) w0[o / 2][t][c][o % 2] = wr[t * 4 + c];
-    }
+    for (int e = 0; e < 16; ++e) bias0[e] = p0.bias[(e & 3) + 8 * (e >> 2) + 4 * kb0];
     // phase-B fragment bookkeeping
     const int kb = lane >> 5, r = wm * 32 + (lane & 31), py = r / TW, px = r - py * TW;
     const int brow = wn * 32 + (lane & 31);
 
+    // the next tile's RGB pixels are fetched into registers while this tile is computed (two 16-byte loads per thread)
+    constexpr int LOADS = (RR * RC + NT - 1) / NT;
+    float4 nxt[LOADS];
+    auto fetch = [&](int tl) {
+        const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
+        const int iy0 = 2 * ((rem / tiles_x) * TH) - 2, ix0 = 2 * ((rem % tiles_x) * TW) - 2;
+#pragma unroll
+        for (int l = 0; l < LOADS; ++l) {
+            const int i = tid + l * NT, rr = i / RC, cc = i - rr * RC;
+            const int iy = iy0 + rr, ix = ix0 + cc;
+            nxt[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < RR * RC && tl < n_tiles && (unsigned)iy < (unsigned)p0.H && (unsigned)ix < (unsigned)p0.W)
+                nxt[l] = *reinterpret_cast<const float4 *>(p0.x + ((size_t)(img * p0.H + iy) * p0.W + ix) * p0.ldx);
+        }
+    };
+    fetch(blockIdx.x);
     for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
         const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
         const int oy0 = (rem / tiles_x) * TH, ox0 = (rem % tiles_x) * TW;
         const int ly0 = 2 * oy0 - 1, lx0 = 2 * ox0 - 1;           // layer-0 pixel of patch (0, 0); the RGB tile starts one before
         __syncthreads();                                        // previous tile: fragments read, epilogue staging consumed
-        for (int i = tid; i < RR * RC; i += NT) {
-            const int rr = i / RC, cc = i - rr * RC;
-            const int iy = ly0 - 1 + rr, ix = lx0 - 1 + cc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)iy < (unsigned)p0.H && (unsigned)ix < (unsigned)p0.W)
-                v = *reinterpret_cast<const float4 *>(p0.x + ((size_t)(img * p0.H + iy) * p0.W + ix) * p0.ldx);
-            rgb[i] = v;
+#pragma unroll
+        for (int l = 0; l < LOADS; ++l) {
+            const int i = tid + l * NT;
+            if (i < RR * RC) {                                  // [hi r g b 0 | lo r g b 0], x * 2^-8 = hi + lo * 2^-11
+                const float v[4] = {nxt[l].x, nxt[l].y, nxt[l].z, 0.f};
+                union { h16x4 h[2]; float4 f; } sp;
+                h16_encode4(v, sp.h[0], sp.h[1]);
+                rgb[i] = sp.f;
+            }
         }
         __syncthreads();
-        // ---- phase A: layer 0 for the 17 x 33 patch, 64 pixels per pass
+        fetch(tl + gridDim.x);
+        // ---- phase A: layer 0 for the 17 x 33 patch as 18 fragments of 32 pixels (wave w takes fragments w, w + 8, w + 16)
 #pragma unroll 1
-        for (int pass = 0; pass < (PATCH_ROWS + 63) / 64; ++pass) {
-            const int pix = pass * 64 + slot;
-            const int ry = min(pix, PATCH_ROWS - 1) / PC, rc = min(pix, PATCH_ROWS - 1) % PC;
-            f32x2 a2[2] = {b0[0], b0[1]};
+        for (int fr = wave; fr < (YDS_STEM_ABL == 1 ? 0 : (PATCH_ROWS + 31) / 32); fr += NW) {
+            const int pix = fr * 32 + (lane & 31), pc = min(pix, PATCH_ROWS - 1);
+            const int ry = pc / PC, rc = pc - ry * PC;
+            f32x16 c1, c2;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float4 v = rgb[(ry + t / 3) * RC + rc + t % 3];
+            for (int e = 0; e < 16; ++e) { c1[e] = 0.f; c2[e] = 0.f; }
 #pragma unroll
-                for (int o = 0; o < 2; ++o) {
-                    a2[o] = __builtin_elementwise_fma(f32x2{v.x, v.x}, w0[o][t][0], a2[o]);
-                    a2[o] = __builtin_elementwise_fma(f32x2{v.y, v.y}, w0[o][t][1], a2[o]);
-                    a2[o] = __builtin_elementwise_fma(f32x2{v.z, v.z}, w0[o][t][2], a2[o]);
+            for (int sb = 0; sb < 3; ++sb) {
+                union { h16x4 q[2]; h8 v; } xh, xl;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int t = 4 * sb + 2 * kb0 + u;             // tap of this half of the lane's 8 k
+                    union { float4 f; h16x4 h[2]; } px4;
+                    px4.f = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (t < 9) px4.f = rgb[(ry + t / 3) * RC + rc + t % 3];
+                    xh.q[u] = px4.h[0];
+                    xl.q[u] = px4.h[1];
+                }
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h[sb], xh.v, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h[sb], xl.v, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l[sb], xh.v, c2, 0, 0, 0);
+            }
+            // this lane: pixel `pix`, channels (e & 3) + 8 (e >> 2) + 4 kb0 -> four 8-byte pieces of hi and of lo
+            const bool inside = pix < PATCH_ROWS && (unsigned)(ly0 + ry) < (unsigned)p0.H && (unsigned)(lx0 + rc) < (unsigned)p0.W;
+            const int j = patch_row(ry, rc), jsw = (j >> 1) & 7;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = g * 4 + c;
+                    const float o = (c1[e] + c2[e] * (1.f / LO_SCALE)) * (1.f / A_SCALE) + bias0[e];
+                    v[c] = inside ? apply_act<ACT0>(o) : 0.f;     // layer 1 zero-pads layer 0's output
+                }
+                h16x4 hi, lo;
+                h16_encode4(v, hi, lo);
+                if (pix < PATCH_ROWS) {
+                    *reinterpret_cast<h16x4 *>(patch + j * 128 + ((g ^ jsw) << 4) + kb0 * 8) = hi;          // chunk g: channels 8g .. 8g+7
+                    *reinterpret_cast<h16x4 *>(patch + j * 128 + (((4 + g) ^ jsw) << 4) + kb0 * 8) = lo;
                 }
             }
-            float acc[4] = {a2[0][0], a2[0][1], a2[1][0], a2[1][1]};
-            const bool inside = (unsigned)(ly0 + ry) < (unsigned)p0.H && (unsigned)(lx0 + rc) < (unsigned)p0.W;
-#pragma unroll
-            for (int o = 0; o < 4; ++o) acc[o] = inside ? apply_act<ACT0>(acc[o]) : 0.f;      // layer 1 zero-pads layer 0's output
-            h16x4 hi, lo;
-            h16_encode4(acc, hi, lo);
-            const bool odd = q & 1;
-            union { h16x4 h; int i[2]; } send, recv;
-            send.h = odd ? hi : lo;
-            recv.i[0] = __shfl_xor(send.i[0], 1);
-            recv.i[1] = __shfl_xor(send.i[1], 1);
-            union { h16x4 h[2]; f32x4 f; } out;
-            out.h[0] = odd ? recv.h : hi;
-            out.h[1] = odd ? lo : recv.h;
-            const int chunk = (odd ? 4 : 0) + (q >> 1);           // hi chunks 0-3 (8 channels each), lo chunks 4-7
-            const int j = patch_row(ry, rc);
-            if (pix < PATCH_ROWS) *reinterpret_cast<f32x4 *>(patch + j * 128 + ((chunk ^ ((j >> 1) & 7)) << 4)) = out.f;
         }
         __syncthreads();
         // ---- phase B: layer 1, 9 taps x 2 k-substeps on the patch
@@ -131,7 +172,7 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc1[0][0][e] = 0.f; acc2[0][0][e] = 0.f; }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < (YDS_STEM_ABL == 2 ? 0 : 9); ++t) {
             const int dy = t / 3, dx = t % 3;
             const int j = (dx & 1) ? ODD_BASE + (2 * py + dy) * ODD_COLS + px : (2 * py + dy) * EVEN_COLS + px + (dx >> 1);
             const int jsw = (j >> 1) & 7, wrow = t * BN + brow, wsw = (wrow >> 1) & 7;
@@ -150,6 +191,7 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[0][0][e] = (acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
         // the staging area (32 x 68 floats) lives in the RGB tile, which phase A is done with
+        if (YDS_STEM_ABL == 3) { if (acc1[0][0][0] == 123.456f) p1.y[0] = 1.f; continue; }
         conv_epilogue_rows<BM, BN, WM, WN, ACT1, RES_NONE, 1, 1, NT, StemRows>(p1, acc1, reinterpret_cast<float *>(rgb),
                                                                                  StemRows{img, oy0, ox0, p1.Ho, p1.Wo}, 0, tid);
     }
