@@ -189,6 +189,151 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_pool(ConvKernelArgs p, int Hp
     }
 }
 
+// The same stem on the matrix cores (f16x3 arithmetic, conv_f16x3.hip): the vector-ALU version above spends its time in
+// 27-deep fma chains and evaluates every convolution output 2.25 times.  Here a 512-thread persistent workgroup owns a
+// 4 x 16 patch of POOLED pixels: the 9 x 33 convolution outputs it needs are computed once as MFMA products (filter
+// fragments = first operand, in registers; pixel fragments gathered from a split RGB tile in LDS as in conv_stem2.hip; a
+// lane ends up with 4 consecutive channels of one pixel), written to LDS as fp32 after bias + activation (-inf where the
+// position lies outside the image: the pool pads with -inf), and pooled from there.
+constexpr int MP_TH = 4, MP_TW = 16;                                // pooled patch
+constexpr int MP_CR = 2 * MP_TH + 1, MP_CC = 2 * MP_TW + 1;         // conv region 9 x 33
+constexpr int MP_IR = MP_CR + 2, MP_IC = MP_CC + 2;                 // input tile 11 x 35
+constexpr int MP_CONV = MP_CR * MP_CC;                              // 297
+constexpr int MP_LD = 68;                                           // floats per conv row in LDS (64 + 4: conflict-free 16-byte accesses)
+constexpr int MP_NT = 512;
+
+template <int ACT>
+__global__ __launch_bounds__(MP_NT, 1) void conv3x3_rgb_pool_mfma(ConvKernelArgs p, int Hp, int Wp, int tiles_y, int tiles_x, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char mp_smem[];
+    float4 *rgb = reinterpret_cast<float4 *>(mp_smem);              // [hi r g b 0 | lo r g b 0] per input pixel
+    float *conv = reinterpret_cast<float *>(mp_smem + MP_IR * MP_IC * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = lane >> 5;
+    // filter fragments of both 32-channel halves (first MFMA operand: row = channel, k = 16 s + 8 kb + 0..7 = taps 4s + 2kb,
+    // 4s + 2kb + 1 x (r, g, b, pad)), split on the fly
+    h8 wh[2][3], wl[2][3];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int t = 4 * sb + 2 * kb + (e >> 2), c = e & 3;
+                const float x = (t < 9 && c < 3) ? p.w[(size_t)(n * 32 + (lane & 31)) * p.Kpad + t * 4 + c] : 0.f;
+                const _Float16 h = (_Float16)x;
+                wh[n][sb][e] = h;
+                wl[n][sb][e] = (_Float16)((x - (float)h) * 2048.f);
+            }
+    constexpr int LOADS = (MP_IR * MP_IC + MP_NT - 1) / MP_NT;
+    float4 nxt[LOADS];
+    auto fetch = [&](int tl) {
+        const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
+        const int iy0 = 2 * ((rem / tiles_x) * MP_TH) - 2, ix0 = 2 * ((rem % tiles_x) * MP_TW) - 2;
+#pragma unroll
+        for (int l = 0; l < LOADS; ++l) {
+            const int i = tid + l * MP_NT, rr = i / MP_IC, cc = i - rr * MP_IC;
+            const int iy = iy0 + rr, ix = ix0 + cc;
+            nxt[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < MP_IR * MP_IC && tl < n_tiles && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                nxt[l] = *reinterpret_cast<const float4 *>(p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.ldx);
+        }
+    };
+    fetch(blockIdx.x);
+    for (int tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
+        const int py0 = (rem / tiles_x) * MP_TH, px0 = (rem % tiles_x) * MP_TW;
+        const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;             // convolution position of conv-region (0, 0)
+        __syncthreads();                                            // previous tile pooled
+#pragma unroll
+        for (int l = 0; l < LOADS; ++l) {
+            const int i = tid + l * MP_NT;
+            if (i < MP_IR * MP_IC) {
+                const float v[4] = {nxt[l].x, nxt[l].y, nxt[l].z, 0.f};
+                union { h16x4 h[2]; float4 f; } sp;
+                h16_encode4(v, sp.h[0], sp.h[1]);
+                rgb[i] = sp.f;
+            }
+        }
+        __syncthreads();
+        fetch(tl + gridDim.x);
+        // convolution: 10 fragments of 32 positions x 2 channel halves = 20 units over 8 waves
+#pragma unroll 1
+        for (int u = wave; u < 2 * ((MP_CONV + 31) / 32); u += 8) {
+            const int fr = u >> 1, n = u & 1;
+            const int pix = fr * 32 + (lane & 31), pc = min(pix, MP_CONV - 1);
+            const int ry = pc / MP_CC, rc = pc - ry * MP_CC;
+            f32x16 c1, c2;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { c1[e] = 0.f; c2[e] = 0.f; }
+#pragma unroll
+            for (int sb = 0; sb < 3; ++sb) {
+                union { h16x4 q[2]; h8 v; } xh, xl;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int t = 4 * sb + 2 * kb + h;
+                    union { float4 f; h16x4 hh[2]; } px4;
+                    px4.f = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (t < 9) px4.f = rgb[(ry + t / 3) * MP_IC + rc + t % 3];
+                    xh.q[h] = px4.hh[0];
+                    xl.q[h] = px4.hh[1];
+                }
+                const h8 fh = n ? wh[1][sb] : wh[0][sb], fl = n ? wl[1][sb] : wl[0][sb];
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, xh.v, c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, xl.v, c2, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, xh.v, c2, 0, 0, 0);
+            }
+            const bool inside = (unsigned)(cy0 + ry) < (unsigned)p.H && (unsigned)(cx0 + rc) < (unsigned)p.W;
+            if (pix < MP_CONV) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = n * 32 + 8 * g + 4 * kb;             // this lane's 4 consecutive channels of group g
+                    const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + ch);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    float o[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float v = (c1[g * 4 + c] + c2[g * 4 + c] * (1.f / 2048.f)) * 256.f + bb[c];
+                        o[c] = inside ? apply_act<ACT>(v) : -INFINITY;
+                    }
+                    *reinterpret_cast<float4 *>(conv + pix * MP_LD + ch) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        __syncthreads();
+        // pooling: 64 pooled pixels x 16 channel quads
+#pragma unroll
+        for (int it = 0; it < MP_TH * MP_TW * 16 / MP_NT; ++it) {
+            const int idx = it * MP_NT + tid, pp = idx >> 4, cq = idx & 15;
+            const int ppy = pp / MP_TW, ppx = pp - ppy * MP_TW;
+            float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int d = 0; d < 9; ++d) {
+                const float4 v = *reinterpret_cast<const float4 *>(conv + ((2 * ppy + d / 3) * MP_CC + 2 * ppx + d % 3) * MP_LD + cq * 4);
+                m[0] = fmaxf(m[0], v.x); m[1] = fmaxf(m[1], v.y); m[2] = fmaxf(m[2], v.z); m[3] = fmaxf(m[3], v.w);
+            }
+            const int Py = py0 + ppy, Px = px0 + ppx;
+            const bool live = Py < Hp && Px < Wp;
+            float *yp = p.y + ((size_t)(img * Hp + (live ? Py : 0)) * Wp + (live ? Px : 0)) * p.ldy;
+            if (p.fmt_y == FMT_H16) {                               // lane pairs trade halves: one 16-byte store per lane
+                h16x4 hi, lo;
+                h16_encode4(m, hi, lo);
+                const bool odd = cq & 1;
+                union { h16x4 h; int i[2]; } send, recv;
+                send.h = odd ? hi : lo;
+                recv.i[0] = __shfl_xor(send.i[0], 1);
+                recv.i[1] = __shfl_xor(send.i[1], 1);
+                union { h16x4 h[2]; float4 f; } out;
+                out.h[0] = odd ? recv.h : hi;
+                out.h[1] = odd ? lo : recv.h;
+                const int c0 = (cq & ~1) * 4;
+                char *g = reinterpret_cast<char *>(yp + (c0 & ~31)) + (c0 & 31) * 2 + (odd ? 64 : 0);
+                if (live) *reinterpret_cast<float4 *>(g) = out.f;
+            } else if (live) {
+                *reinterpret_cast<float4 *>(yp + cq * 4) = make_float4(m[0], m[1], m[2], m[3]);
+            }
+        }
+    }
+}
+
 bool conv_pool_applicable(const ConvKernelArgs &k) {
     return k.Cin == 4 && k.ksize == 3 && k.stride == 1 && k.pad == 1 && k.Cout == 64 && k.res_mode == RES_NONE && k.fmt_x == FMT_F32;
 }
@@ -198,6 +343,24 @@ void launch_conv_pool(const ConvKernelArgs &k, hipStream_t s) {
     if (!conv_pool_applicable(k)) fail("conv+pool: only the 3x3 RGB stem with 64 filters is fused");
     const int Hp = (k.H + 2 - 3) / 2 + 1, Wp = (k.W + 2 - 3) / 2 + 1, n_img = k.M / (k.H * k.W);
     const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW, n_tiles = n_img * tiles_y * tiles_x;
+    if (conv_math() == MATH_F16X3 && !getenv("YDS_POOL_VALU")) {    // matrix-core version (exact fp32 mode keeps the fma chain)
+        const int ty = (Hp + MP_TH - 1) / MP_TH, tx = (Wp + MP_TW - 1) / MP_TW, nt = n_img * ty * tx;
+        dim3 g((unsigned)std::min(nt, 256));
+        constexpr int smem = MP_IR * MP_IC * 16 + MP_CONV * MP_LD * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_rgb_pool_mfma<ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_rgb_pool_mfma<ACT_LEAKY>), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        switch (k.act) {
+            case ACT_RELU: hipLaunchKernelGGL((conv3x3_rgb_pool_mfma<ACT_RELU>), g, dim3(MP_NT), smem, s, k, Hp, Wp, ty, tx, nt); break;
+            case ACT_LEAKY: hipLaunchKernelGGL((conv3x3_rgb_pool_mfma<ACT_LEAKY>), g, dim3(MP_NT), smem, s, k, Hp, Wp, ty, tx, nt); break;
+            default: fail("conv+pool: unsupported activation %d", k.act);
+        }
+        YDS_HIP(hipGetLastError());
+        return;
+    }
     dim3 grid((unsigned)std::min(n_tiles, 256 * 8));
     switch (k.act) {
         case ACT_RELU: hipLaunchKernelGGL((conv3x3_rgb_pool<64, ACT_RELU>), grid, dim3(256), 0, s, k, Hp, Wp, tiles_y, tiles_x, n_tiles); break;
