@@ -174,6 +174,9 @@ ConvKernelArgs make_conv_args(const ConvArgs &a);
 // fused detector stem (conv_stem2.hip): 3x3/s1 RGB conv (direct, vector ALU) + 3x3/s2 32->64 conv (f16x3 MFMA) in one kernel
 bool conv_stem2_applicable(const ConvKernelArgs &k0, const ConvKernelArgs &k1);
 void launch_conv_stem2(const ConvKernelArgs &k0, const ConvKernelArgs &k1, hipStream_t s);
+// fused first residual block (conv_block1.hip): conv1x1 64->32 + conv3x3 32->64 + shortcut to the block input
+bool conv_block1_applicable(const ConvKernelArgs &k2, const ConvKernelArgs &k3);
+void launch_conv_block1(const ConvKernelArgs &k2, const ConvKernelArgs &k3, hipStream_t s);
 
 // dispatch on (activation, residual mode) to the compile-time epilogue instantiation of launcher L<ACT, RES>
 #define YDS_DISPATCH_ACT_RES(k, CALL)                                                                     \

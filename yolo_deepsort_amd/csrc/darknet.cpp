@@ -187,6 +187,13 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
     // the first two convolutions can run as one kernel (conv_stem2.hip) when only layer 1 reads layer 0
     stem_fusable = L >= 2 && layers[0].type == "convolutional" && layers[1].type == "convolutional" && readers[0] == 1 &&
                    layers[1].src == 0 && layers[0].fused_res < 0 && layers[1].fused_res < 0;
+    // ... and so can the first residual block (conv_block1.hip): conv a (read only by conv b), conv b absorbing the
+    // shortcut back to conv a's input
+    for (int i = 1; i + 1 < L && block1_at < 0; ++i)
+        if (layers[i].type == "convolutional" && layers[i + 1].type == "convolutional" && readers[i] == 1 && layers[i + 1].src == i &&
+            layers[i].fused_res < 0 && layers[i + 1].fused_res >= 0 && layers[i + 1].fused_res == layers[i].src && layers[i].ksize == 1 &&
+            layers[i + 1].ksize == 3)
+            block1_at = i;
     // single-source routes are views
     for (int i = 0; i < L; ++i) {
         Layer &l = layers[i];
@@ -440,6 +447,7 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
             if (!l.loaded) fail("forward: layer %d has no weights (call load_darknet_weights)", i);
             ConvArgs a = conv_args(i, batch);
             if (i == 0 && stem_fused(batch)) continue;              // computed inside layer 1's launch
+            if (i == block1_at && block1_fused(batch)) continue;    // computed inside the next layer's launch
             if (time_convs) YDS_HIP(hipEventRecord(ev0, stream));
             int variant;
             if (i == 1 && stem_fused(batch)) {
@@ -449,6 +457,14 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
                 launch_conv_stem2(k0, k1, stream);
                 variant = kDirectVariant;                           // accounted with the direct first-layer kernel
                 if (time_convs) conv_flops_acc[variant] += conv_flops(a0);
+            } else if (i == block1_at + 1 && block1_at >= 0 && block1_fused(batch)) {
+                ConvArgs a2 = conv_args(block1_at, batch);
+                ConvKernelArgs k2 = make_conv_args(a2), k3 = make_conv_args(a);
+                k2.w = reinterpret_cast<const float *>(a2.w16);
+                k3.w = reinterpret_cast<const float *>(a.w16);
+                launch_conv_block1(k2, k3, stream);
+                variant = kF32Variants + 8;                         // accounted with the window-resident 3x3 kernel
+                if (time_convs) conv_flops_acc[variant] += conv_flops(a2);
             } else {
                 variant = launch_conv(a, stream, l.variant);
             }
@@ -560,9 +576,24 @@ bool Darknet::stem_fused(int batch) {
     return stem_ok;
 }
 
+bool Darknet::block1_fused(int batch) {
+    static const bool off = getenv("YDS_NO_BLOCK_FUSE") != nullptr;
+    if (off || block1_at < 0 || conv_math() != MATH_F16X3 || !layers[block1_at].loaded || !layers[block1_at + 1].loaded) return false;
+    if (block1_checked != batch) {
+        ConvArgs a2 = conv_args(block1_at, batch), a3 = conv_args(block1_at + 1, batch);
+        block1_ok = a2.w16 && a3.w16 && conv_block1_applicable(make_conv_args(a2), make_conv_args(a3));
+        block1_checked = batch;
+    }
+    return block1_ok;
+}
+
 void Darknet::layer_output_host(int i, int batch, float *nchw) {
     if (i < 0 || i >= (int)layers.size()) fail("layer_output: no layer %d", i);
     const Layer &l = layers[i];
+    if (i == block1_at && block1_fused(batch)) {                  // never written by the fused block: produce it on demand
+        ConvArgs a2 = conv_args(i, batch);
+        (void)launch_conv(a2, stream, layers[i].variant);
+    }
     if (i == 0 && stem_fused(batch)) {                            // the fused stem never writes layer 0: produce it on demand
         ConvArgs a0 = conv_args(0, batch);
         (void)launch_conv(a0, stream, layers[0].variant);

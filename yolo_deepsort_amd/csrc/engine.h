@@ -109,6 +109,9 @@ private:
     bool stem_fusable = false, stem_ok = false;               // layers 0+1 as one kernel (conv_stem2.hip)
     int stem_checked = -1;
     bool stem_fused(int batch);
+    int block1_at = -1, block1_checked = -1;                  // first conv of the fused residual block (conv_block1.hip), -1: none
+    bool block1_ok = false;
+    bool block1_fused(int batch);
     hipEvent_t out_guard = nullptr;                           // optional: event the decode waits for before it overwrites `out`
     int lane_img0 = 0;                                        // image offset applied by view() / input_view() while a lane is enqueued
     std::vector<hipStream_t> lane_streams;
