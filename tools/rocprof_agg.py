@@ -12,7 +12,7 @@ from collections import OrderedDict
 
 
 def key_of(name):
-    m = re.match(r"void yds::(?:\(anonymous namespace\)::)?(conv3x3_f16x3_win|conv_igemm_f16x3_dma|conv_igemm_f16x3|conv_igemm_f32|conv3x3_rgb_direct|conv3x3_rgb_pool|conv_stem2_f16x3)<([^>]*)>", name)
+    m = re.match(r"void yds::(?:\(anonymous namespace\)::)?(conv3x3_f16x3_win|conv_igemm_f16x3_dma|conv_igemm_f16x3|conv_igemm_f32|conv3x3_rgb_direct|conv3x3_rgb_pool_mfma|conv3x3_rgb_pool|conv_stem2_f16x3|conv_block1_f16x3)<([^>]*)>", name)
     if not m:
         return None
     kind, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
