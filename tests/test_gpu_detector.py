@@ -269,3 +269,27 @@ def test_lane_split_matches_single_stream(monkeypatch):
     net1, _ = _nets(cfg, 416, 0, obj_bias=-1.0, batch_max=1)
     for b in (0, 4, 5, 8):
         _close(outs["2"][b:b + 1], np.asarray(net1(x[b:b + 1])), rtol=1e-4, atol=1e-4, msg=f"image {b}")
+
+
+@pytest.mark.parametrize("name", ["yolov3", "yolov4"])
+def test_fused_stem_and_first_block_layers_vs_oracle(name):
+    """conv_stem2.hip (layers 0+1) and conv_block1.hip (first 1x1 / 3x3 / shortcut block) replace several launches: their
+    outputs, and the on-demand recomputation of the layers they no longer write, against the oracle's layer outputs.
+    Odd image size: ragged patches, borders in every tile; batch 2."""
+    size = (160, 96)
+    cfg = cfgs.cfg_text(name, size[0], size[1])
+    net, ref = _nets(cfg, size, 5, -2.0, batch_max=2)
+    x = np.random.RandomState(6).uniform(0, 1, (2, 3) + size).astype(F32)
+    out = np.asarray(net(x))
+    ref.forward(x, keep_layers=True)
+    checked = 0
+    for i, d in enumerate(ref.module_defs[:9]):
+        try:
+            got = net.layer_output(i, 2)
+        except Exception as e:                      # conv fused with the following shortcut
+            assert "fused" in str(e)
+            continue
+        _close(got, ref.layer_outputs[i], 1e-3, 1e-3, f"{name} layer {i} {d['type']}")
+        checked += 1
+    assert checked >= 6
+    _close(out, ref.forward(x))
