@@ -315,26 +315,26 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *cost, int nr0, in
         while (sink == -1) {
             if (lane == 0) SR[i] = 1;
             const double ui = u[i];
+            // one pass, one reduction: the candidate is the lexicographic minimum of (shortest path cost, key) where the key
+            // encodes scipy's tie-break - among equal costs the LAST unassigned column in `remaining` order, otherwise the
+            // FIRST column: unassigned -> 0x3fffffff - it (larger it = smaller key), assigned -> 0x40000000 + it
             double lmin = INFINITY;
+            int lkey = 0x7fffffff;
             for (int it = lane; it < num_remaining; it += 64) {
                 int j = remaining[it];
                 double r = minVal + C(i, j) - ui - v[j];
                 double s = spc[j];
                 if (r < s) { path[j] = i; spc[j] = r; s = r; }
-                lmin = fmin(lmin, s);
+                const int key = row4col[j] == -1 ? 0x3fffffff - it : 0x40000000 + it;
+                if (s < lmin || (s == lmin && key < lkey)) { lmin = s; lkey = key; }
             }
-            const double lowest = wave_min(lmin);
-            int last_free = -1, first_any = 0x7fffffff;
-            for (int it = lane; it < num_remaining; it += 64) {
-                int j = remaining[it];
-                if (spc[j] == lowest) {
-                    first_any = min(first_any, it);
-                    if (row4col[j] == -1) last_free = max(last_free, it);
-                }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double os = __shfl_xor(lmin, o, 64);
+                const int ok = __shfl_xor(lkey, o, 64);
+                if (os < lmin || (os == lmin && ok < lkey)) { lmin = os; lkey = ok; }
             }
-            last_free = wave_max_i(last_free);
-            first_any = wave_min_i(first_any);
-            const int index = last_free >= 0 ? last_free : first_any;
+            const double lowest = lmin;
+            const int index = lkey < 0x40000000 ? 0x3fffffff - lkey : lkey - 0x40000000;
             minVal = lowest;
             const int j = remaining[index];
             const int owner = row4col[j];
