@@ -66,6 +66,20 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` on its own launches the N ranks itself (one process per GPU, rendezvous on 127.0.0.1);
+    # under torch.distributed.run (the driver's launch line) WORLD_SIZE is already set and this is one of the ranks
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}; launch one rank per GPU")
+
     import torch
     from yolo_deepsort_amd.dist import Ranks
     ranks = Ranks("nccl")
@@ -137,6 +151,7 @@ def main():
     sync()
     dt = ranks.max_over_ranks(time.perf_counter() - t0)
     n_out = int(ranks.sum_over_ranks(n_out))
+    rank_devices = ranks.gather_objects((_lib.current_device(), _lib.pci_bus_id()))
     stage = pipe.stage_us()
 
     roofline, variants = None, None
@@ -187,7 +202,8 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x3" if _lib.load().yds_get_conv_math() == 1 else "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "frames_per_step": B, "streams": world, "frame": "1920x1080x3 u8",
-                       "tracker_rows_out": n_out, "parallelism": f"stream-per-gpu x{world}"},
+                       "tracker_rows_out": n_out, "parallelism": f"stream-per-gpu x{world}",
+                       "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices]},
             "stage_us_last_step": {k: round(v, 1) for k, v in stage.items()},
             "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
             "roofline": roofline, "conv_variants": variants, "cpu_baseline": cpu,

@@ -33,7 +33,13 @@ typedef struct yds_trk yds_trk;     /* DeepSORT tracker      (deep_sort/sort/tra
 typedef struct yds_pipe yds_pipe;   /* detect+ReID+associate (yolo3/detect/video_detect.py:134-157) */
 
 /* ---- runtime -------------------------------------------------------------------------- */
-int yds_init(int device_id);                 /* hipSetDevice + capability check (gfx950)        */
+/* Binds the PROCESS to one GPU (hipSetDevice + gfx950 check).  Multi-GPU runs are one process per GPU (bench.py /
+ * torch.distributed.run: device = LOCAL_RANK); the reference has no device-selection API of its own besides
+ * `.to(device)` (yolo3/detect/img_detect.py:45-48).  device_id < 0 = keep the device already bound (0 if none).
+ * A second call with a different device fails: handles, streams and buffers of this library live on the bound GPU. */
+int yds_init(int device_id);
+int yds_current_device(void);                /* device bound by yds_init, -1 before                       */
+int yds_device_pci_bus_id(char *buf, int len); /* "0000:xx:00.0" of the bound device (rank placement checks) */
 const char *yds_last_error(void);            /* thread-local message of the last failing call   */
 int yds_device_count(void);
 const char *yds_build_info(void);            /* "libydsort <ver> gfx950 ..."                    */

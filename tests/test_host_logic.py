@@ -140,6 +140,7 @@ r.barrier()
 dt = r.max_over_ranks(1.0 + r.rank)            # slowest rank defines the job time
 tot = r.sum_over_ranks(float(boxes[:, 0].sum()))
 frames = r.total_frames(10, 8)
+assert r.gather_objects(("r", r.rank)) == [("r", 0), ("r", 1)]
 if r.rank == 0:
     other = synth.PersonScene(5, seed=1).boxes(0)[1]
     assert dt == 2.0 and frames == 160

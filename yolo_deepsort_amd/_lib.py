@@ -31,6 +31,8 @@ SIGNATURES = {
     "yds_init": (_I, [_I]),
     "yds_last_error": (C.c_char_p, []),
     "yds_device_count": (_I, []),
+    "yds_current_device": (_I, []),
+    "yds_device_pci_bus_id": (_I, [C.c_char_p, _I]),
     "yds_build_info": (C.c_char_p, []),
     "yds_dev_alloc": (_P, [_SZ]),
     "yds_dev_free": (_I, [_P]),
@@ -136,15 +138,42 @@ def check_ptr(p):
     return p
 
 
-_initialised = {}
+_bound = None
 
 
-def init(device=0):
-    """yds_init once per process/device; raises when no MI355X is visible."""
-    if _initialised.get(device):
-        return
-    check(load().yds_init(int(device)))
-    _initialised[device] = True
+def default_device():
+    """Device of this process when the caller names none: YDS_DEVICE, else LOCAL_RANK (one process per GPU under
+    torch.distributed.run), else 0."""
+    for key in ("YDS_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v not in (None, ""):
+            return int(v)
+    return 0
+
+
+def init(device=None):
+    """Bind this process to ONE GPU (yds_init); raises when no MI355X is visible.  ``device=None`` keeps the device
+    that is already bound, or picks ``default_device()`` on the first call.  Asking for a different device after the
+    first call raises: every handle of the process lives on the bound GPU (multi-GPU = one process per GPU)."""
+    global _bound
+    if _bound is not None:
+        if device is not None and int(device) != _bound:
+            raise YdsError(f"this process is bound to device {_bound}; one process drives one GPU (requested {int(device)})")
+        return _bound
+    dev = default_device() if device is None else int(device)
+    check(load().yds_init(dev))
+    _bound = dev
+    return dev
+
+
+def current_device():
+    return _bound
+
+
+def pci_bus_id():
+    buf = C.create_string_buffer(64)
+    check(load().yds_device_pci_bus_id(buf, 64))
+    return buf.value.decode()
 
 
 def ptr(a):

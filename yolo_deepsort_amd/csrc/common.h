@@ -15,6 +15,8 @@ struct Error : std::runtime_error {
     explicit Error(const std::string &m) : std::runtime_error(m) {}
 };
 [[noreturn]] void fail(const char *fmt, ...);
+int bound_device();     // device yds_init bound this process to, -1 before
+void bind_thread();     // selects that device for the calling host thread (hipSetDevice is per thread)
 
 #define YDS_HIP(expr)                                                                          \
     do {                                                                                       \
@@ -24,7 +26,7 @@ struct Error : std::runtime_error {
     } while (0)
 
 // Runs `body`, converts C++ exceptions into the C ABI's status code.
-#define YDS_API_BEGIN try {
+#define YDS_API_BEGIN try { ::yds::bind_thread();
 #define YDS_API_END                                                                            \
     }                                                                                          \
     catch (const std::exception &e) {                                                          \

@@ -1,6 +1,7 @@
 // Runtime plumbing of libydsort: error reporting, device selection, raw HBM buffers.
 #include "common.h"
 
+#include <atomic>
 #include <stdarg.h>
 #include <string.h>
 
@@ -9,6 +10,20 @@ namespace yds {
 static thread_local std::string g_last_error;
 
 void set_error(const std::string &msg) { g_last_error = msg; }
+
+// One process drives one GPU (multi-GPU = one process per GPU).  yds_init() binds the process to a device
+// once; hipSetDevice is per host thread, so every ABI entry re-selects the bound device for the calling thread.
+static std::atomic<int> g_device{-1};
+static thread_local int t_device = -1;
+
+int bound_device() { return g_device.load(); }
+
+void bind_thread() {
+    const int d = g_device.load();
+    if (d >= 0 && t_device != d) {
+        if (hipSetDevice(d) == hipSuccess) t_device = d;
+    }
+}
 
 void fail(const char *fmt, ...) {
     char buf[1024];
@@ -25,7 +40,9 @@ extern "C" {
 
 const char *yds_last_error(void) { return yds::g_last_error.c_str(); }
 
-const char *yds_build_info(void) { return "libydsort 0.1 (HIP, gfx950, fp32 MFMA implicit-GEMM conv)"; }
+const char *yds_build_info(void) {
+    return "libydsort 0.2 (HIP, gfx950; conv: f16x3 split-fp16 MFMA 32x32x16 [default], exact fp32 MFMA, f16 single-term half mode)";
+}
 
 int yds_device_count(void) {
     int n = 0;
@@ -38,12 +55,28 @@ int yds_init(int device_id) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) yds::fail("no HIP device visible (%s); libydsort has no CPU path", hipGetErrorString(e));
-    if (device_id < 0 || device_id >= n) yds::fail("device %d outside [0,%d)", device_id, n);
+    const int bound = yds::g_device.load();
+    if (device_id < 0) device_id = bound >= 0 ? bound : 0;                    /* "whatever is already selected" */
+    if (device_id >= n) yds::fail("device %d outside [0,%d)", device_id, n);
+    if (bound >= 0 && bound != device_id)
+        yds::fail("this process is already bound to device %d; one process drives one GPU (requested %d)", bound, device_id);
     YDS_HIP(hipSetDevice(device_id));
     hipDeviceProp_t prop;
     YDS_HIP(hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         yds::fail("device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+    yds::g_device.store(device_id);
+    yds::t_device = device_id;
+    YDS_API_END
+}
+
+int yds_current_device(void) { return yds::g_device.load(); }
+
+int yds_device_pci_bus_id(char *buf, int len) {
+    YDS_API_BEGIN
+    const int d = yds::g_device.load();
+    if (d < 0) yds::fail("yds_init has not been called");
+    YDS_HIP(hipDeviceGetPCIBusId(buf, len, d));
     YDS_API_END
 }
 

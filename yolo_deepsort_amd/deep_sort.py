@@ -29,7 +29,7 @@ class Extractor:
     """ReID feature extractor; ``model_path`` is a ckpt.t7 (``net_dict``) or a state dict."""
 
     def __init__(self, model_path, use_cuda=True, max_crops=256):
-        _lib.init(0)
+        _lib.init()
         lib = _lib.load()
         self.device = "cuda"
         self.size = (64, 128)
@@ -198,7 +198,7 @@ class DeepSort(object):
         self.use_cuda = use_cuda
         if nms_max_overlap != 1:
             raise NotImplementedError("tracker-side NMS (nms_max_overlap != 1) is out of scope (SURVEY 2 #9)")
-        _lib.init(0)
+        _lib.init()
         if isinstance(model_path, (str, dict)):
             self.extractor = Extractor(model_path, use_cuda=use_cuda)
         else:

@@ -53,6 +53,14 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def gather_objects(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (small host objects: device ids, per-rank rates)."""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def total_frames(self, steps, frames_per_step):
         """Whole-job work: every rank processes steps x frames_per_step frames (weak scaling)."""
         return steps * frames_per_step * self.world

@@ -31,7 +31,7 @@ class _Param:
 
 class Darknet:
     def __init__(self, config_path, img_size=416, batch_max=1, cfg_text=None):
-        _lib.init(0)
+        _lib.init()            # the device this process is bound to (LOCAL_RANK under torch.distributed.run)
         if cfg_text is None:
             with open(config_path, "r") as f:
                 cfg_text = f.read()
@@ -43,7 +43,7 @@ class Darknet:
         self.seen = 0
         self.header_info = np.array([0, 0, 0, self.seen, 0], dtype=np.int32)
         self.batch_max = int(batch_max)
-        self.device = "cuda:0"
+        self.device = f"cuda:{_lib.current_device()}"
         self._half = False
         self._h = None
         self._create()
@@ -103,7 +103,7 @@ class Darknet:
         return self
 
     def cuda(self):
-        return self.to("cuda:0")
+        return self.to(f"cuda:{_lib.current_device()}")
 
     def eval(self):
         return self
