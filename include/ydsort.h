@@ -66,6 +66,10 @@ int yds_device_sync(void);
 yds_net *yds_darknet_create(const char *cfg_text, int img_h, int img_w, int batch_max);
 void yds_darknet_destroy(yds_net *);
 int yds_darknet_load_weights(yds_net *, const void *blob_host, size_t nbytes, int cutoff);
+/* Re-sizes the activation buffers for a larger (or smaller) batch INSIDE the handle: weights, plan and every pointer
+ * to the handle (pipelines) stay valid.  The reference's Darknet takes any batch size (models.py:292). */
+int yds_darknet_set_batch_max(yds_net *, int batch_max);
+int yds_darknet_batch_max(const yds_net *);
 int yds_darknet_num_boxes(const yds_net *);
 int yds_darknet_num_attrs(const yds_net *);                 /* 5 + classes                     */
 int yds_darknet_num_layers(const yds_net *);

@@ -38,10 +38,40 @@ def test_reid_checkpoint_roundtrip_zip_and_legacy():
         torch.save({"net_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "acc": 0.5, "epoch": 1},
                    f.name, _use_new_zipfile_serialization=not legacy)
         back = loaders.load_reid_checkpoint(f.name)
+        full = loaders.read_torch_checkpoint(f.name)
+        # the reader needs no torch: same result in an interpreter where importing torch fails
+        code = ("import sys; sys.modules['torch'] = None; sys.path.insert(0, %r)\n"
+                "import numpy as np\nfrom yolo_deepsort_amd import loaders\n"
+                "sd = loaders.load_reid_checkpoint(%r)\nprint(len(sd), float(sum(np.abs(v).sum() for v in sd.values())))\n" % (ROOT, f.name))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
         os.unlink(f.name)
+        assert out.returncode == 0, out.stderr[-1500:]
+        n, tot = out.stdout.split()
+        assert int(n) == 130 and abs(float(tot) - float(sum(np.abs(v).sum() for v in sd.values()))) < 1e-2
+        assert full["acc"] == 0.5 and full["epoch"] == 1
         assert set(back) == set(sd)
         for k in sd:
-            assert np.array_equal(back[k], sd[k]), k
+            assert np.array_equal(back[k], sd[k]) and back[k].dtype == np.asarray(sd[k]).dtype and back[k].shape == np.asarray(sd[k]).shape, k
+
+
+def test_checkpoint_reader_refuses_code():
+    """A pickle that names anything but tensors/containers is rejected instead of executed."""
+    import pickle
+    import zipfile
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned",))
+    with tempfile.NamedTemporaryFile(suffix=".t7", delete=False) as f:
+        pass
+    with zipfile.ZipFile(f.name, "w") as z:
+        z.writestr("archive/data.pkl", pickle.dumps({"net_dict": Evil()}, protocol=2))
+        z.writestr("archive/version", "3")
+    try:
+        with pytest.raises(pickle.UnpicklingError):
+            loaders.read_torch_checkpoint(f.name)
+    finally:
+        os.unlink(f.name)
 
 
 def test_weight_blob_layout():

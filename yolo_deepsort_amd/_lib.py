@@ -42,6 +42,8 @@ SIGNATURES = {
     "yds_darknet_create": (_P, [C.c_char_p, _I, _I, _I]),
     "yds_darknet_destroy": (None, [_P]),
     "yds_darknet_load_weights": (_I, [_P, _P, _SZ, _I]),
+    "yds_darknet_set_batch_max": (_I, [_P, _I]),
+    "yds_darknet_batch_max": (_I, [_P]),
     "yds_darknet_num_boxes": (_I, [_P]),
     "yds_darknet_num_attrs": (_I, [_P]),
     "yds_darknet_num_layers": (_I, [_P]),

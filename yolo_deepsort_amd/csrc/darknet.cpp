@@ -259,13 +259,24 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
                 int off = 0, o = owner_of(cp.first, off);
                 if (o >= 0 && h16_ok[o] != h16_ok[i]) h16_ok[o] = h16_ok[i] = 0;
             }
-    size_t total_floats = 0;
     for (int i = 0; i < L; ++i) {
         Layer &l = layers[i];
         bool owns = (is_producer(i) && !storage[i].redirected) || (l.type == "route" && l.refs.size() > 1);
         if (!owns) continue;
         if (storage[i].ld == 0) storage[i].ld = (l.c + 3) / 4 * 4;
         storage[i].fmt = (h16_ok[i] && storage[i].ld % 32 == 0) ? FMT_H16 : FMT_F32;
+        storage[i].owns = true;
+    }
+    allocate_buffers();
+}
+
+// Everything whose size depends on batch_max.  set_batch_max() re-runs it inside the SAME object, so handles held by
+// others (a pipeline, the Python wrapper) stay valid when a caller later sends a larger batch.
+void Darknet::allocate_buffers() {
+    size_t total_floats = 0;
+    for (size_t i = 0; i < layers.size(); ++i) {
+        if (!storage[i].owns) continue;
+        const Layer &l = layers[i];
         size_t n = (size_t)batch_max * l.h * l.w * storage[i].ld;
         storage[i].buf.alloc(n);
         YDS_HIP(hipMemsetAsync(storage[i].buf.p, 0, n * sizeof(float), stream));
@@ -276,8 +287,22 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
     stage_f32.alloc((size_t)batch_max * img_h * img_w * 4);
     activation_bytes = total_floats * sizeof(float);
     YDS_HIP(hipStreamSynchronize(stream));
+    inject_rows.clear();
     inject_rows.resize(batch_max);
     inject_n.assign(batch_max, 0);
+    inject_active = false;                                       // injection tables are laid out per batch slot
+    inject_offsets.clear();
+    inject_set = -1;
+    stem_checked = block1_checked = -1;
+    stage_n = 0;
+}
+
+void Darknet::set_batch_max(int b) {
+    if (b < 1) fail("set_batch_max: %d", b);
+    if (b == batch_max) return;
+    YDS_HIP(hipStreamSynchronize(stream));
+    batch_max = b;
+    allocate_buffers();
 }
 
 Darknet::~Darknet() {
@@ -553,6 +578,7 @@ void Darknet::forward_tiles_host(const uint8_t *frame, int h, int w, const int *
     tile_scale.ensure((size_t)n_tiles * 2);
     tiled_pred.ensure((size_t)n_tiles * total_boxes * attrs);
     YDS_HIP(hipMemcpyAsync(stage_u8.p, frame, nbytes, hipMemcpyHostToDevice, stream));
+    stage_h = h; stage_w = w; stage_n = 1;                      // stage_u8 now holds exactly this frame
     YDS_HIP(hipMemcpyAsync(tile_rects.p, tiles, (size_t)n_tiles * 4 * sizeof(int), hipMemcpyHostToDevice, stream));
     YDS_HIP(hipMemcpyAsync(tile_scale.p, scale.data(), scale.size() * sizeof(float), hipMemcpyHostToDevice, stream));
     for (int t0 = 0; t0 < n_tiles; t0 += batch_max) {
@@ -683,6 +709,12 @@ int yds_darknet_load_weights(yds_net *n, const void *blob, size_t nbytes, int cu
     n->d->load_weights(blob, nbytes, cutoff);
     YDS_API_END
 }
+int yds_darknet_set_batch_max(yds_net *n, int batch_max) {
+    YDS_API_BEGIN
+    n->d->set_batch_max(batch_max);
+    YDS_API_END
+}
+int yds_darknet_batch_max(const yds_net *n) { return n->d->batch_max; }
 int yds_darknet_num_boxes(const yds_net *n) { return n->d->total_boxes; }
 int yds_darknet_num_attrs(const yds_net *n) { return n->d->attrs; }
 int yds_darknet_num_layers(const yds_net *n) { return (int)n->d->layers.size(); }

@@ -43,6 +43,7 @@ struct Storage {
     DevBuf<float> buf;
     int ld = 0;
     int fmt = 0;                          // TensorFmt of the owned buffer (H16 only in f16x3 mode, 32-channel granularity)
+    bool owns = false;                    // this layer owns `buf` (sized by batch_max)
     bool redirected = false;              // producer writes into a slice of storage[into]
     int into = -1, coff = 0;
 };
@@ -52,6 +53,7 @@ public:
     Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_max);
     ~Darknet();
     void load_weights(const void *blob, size_t nbytes, int cutoff);
+    void set_batch_max(int b);               // re-sizes the activation buffers in place (weights, plan and handle stay)
     void forward_f32_host(const float *nchw, int batch, float *out_host);
     void forward_u8_host(const uint8_t *frames, int h, int w, int batch, float *out_host);
     void forward_u8_dev(const uint8_t *frames_dev, int h, int w, int batch);
@@ -104,6 +106,7 @@ public:
     int64_t conv_launches[kConvVariants] = {};
 
 private:
+    void allocate_buffers();
     void run_graph(int batch);
     void run_lane(int first, int batch, hipStream_t st);      // layers over images [first, first + batch) on one stream
     bool stem_fusable = false, stem_ok = false;               // layers 0+1 as one kernel (conv_stem2.hip)
@@ -131,6 +134,9 @@ public:
     void launch(const float *pred_dev, size_t pred_stride, int n_frames, int n_boxes, int attrs, float conf_thres, float iou_thres,
                 float sx, float sy, int cap, hipStream_t s);
     int collect(int frame, float *out6_host, int cap);
+    void resize(int max_candidates, int n_frames);       // (re)allocates; contents are lost
+    int needed(int n_frames) const;                       // largest candidate count of the last launch (after the caller's sync)
+    static constexpr int kMaxCandidates = 1 << 18;
     // returns number of rows written to out6_host (<= cap); rows sorted by score, boxes in model pixels
     // scaled by (sx, sy) when scale is requested (resize_boxes).
     int run(const float *pred_dev, int n_boxes, int attrs, float conf_thres, float iou_thres, float sx, float sy,
@@ -164,6 +170,8 @@ public:
     void preprocess_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *nchw_host);
     void forward_f32_host(const float *nchw, int D, float *out_host);
     void forward(int D);                     // input already in `in` (NHWC4)
+    void reserve(int D);                     // grows the activation buffers (and `feat`) to hold D crops
+    void allocate_buffers();
     static int64_t flops_per_crop();
 
     struct ConvW {

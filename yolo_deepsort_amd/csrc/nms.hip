@@ -200,14 +200,32 @@ __global__ void nms_sweep_kernel(const float *sorted_all, const unsigned long lo
     if (threadIdx.x == 0) counts[1] = n_keep;
 }
 
-NmsWorkspace::NmsWorkspace(int max_candidates, int frames) : max_cand(max_candidates), frames(frames) {
+NmsWorkspace::NmsWorkspace(int max_candidates, int frames) : max_cand(0), frames(0) { resize(max_candidates, frames); }
+
+// The reference has no candidate limit (model_build.py:93-121 works on whatever passes the threshold); the workspace
+// grows instead of failing.  The suppression bit matrix is max_cand^2 / 8 bytes per frame, which bounds what is
+// practical: 262144 candidates = 8.6 GB (the reference's O(n^2) greedy loop would need hours there).
+void NmsWorkspace::resize(int max_candidates, int n_frames) {
+    int m = 1024;
+    while (m < max_candidates) m *= 2;
+    if (m > kMaxCandidates) fail("nms: %d candidates per image exceed the supported %d (raise conf_thres)", max_candidates, kMaxCandidates);
+    if (m == max_cand && n_frames == frames) return;
+    max_cand = m; frames = n_frames;
     cand.alloc((size_t)frames * max_cand * 6);
     sorted.alloc((size_t)frames * max_cand * 6);
     counts.alloc((size_t)frames * 4);
     mask.alloc((size_t)frames * max_cand * (max_cand / 64));
     kept.alloc((size_t)frames * MAX_DET * 6);
+    if (h_counts) (void)hipHostFree(h_counts);
+    if (h_kept) (void)hipHostFree(h_kept);
     YDS_HIP(hipHostMalloc((void **)&h_counts, (size_t)frames * 4 * sizeof(int)));
     YDS_HIP(hipHostMalloc((void **)&h_kept, (size_t)frames * MAX_DET * 6 * sizeof(float)));
+}
+
+int NmsWorkspace::needed(int n_frames) const {
+    int m = 0;
+    for (int f = 0; f < n_frames; ++f) m = std::max(m, h_counts[f * 4]);
+    return m;
 }
 
 NmsWorkspace::~NmsWorkspace() {
@@ -219,7 +237,8 @@ NmsWorkspace::~NmsWorkspace() {
 void NmsWorkspace::launch(const float *pred_dev, size_t pred_stride, int n_frames, int n_boxes, int attrs, float conf_thres, float iou_thres,
                           float sx, float sy, int cap, hipStream_t s) {
     if (attrs < 6) fail("nms: predictions need at least one class");
-    if (n_frames < 1 || n_frames > frames) fail("nms: %d frames outside the workspace capacity %d", n_frames, frames);
+    if (n_frames < 1) fail("nms: no frames");
+    if (n_frames > frames) resize(max_cand, n_frames);
     box_count.ensure((size_t)frames * n_boxes);
     const int nb = (n_boxes + 255) / 256;
     hipLaunchKernelGGL(nms_count_kernel, dim3(nb, n_frames), dim3(256), 0, s, pred_dev, pred_stride, n_boxes, attrs, conf_thres, box_count.p);
@@ -239,7 +258,7 @@ void NmsWorkspace::launch(const float *pred_dev, size_t pred_stride, int n_frame
 
 int NmsWorkspace::collect(int frame, float *out6_host, int cap) {
     const int *c = h_counts + frame * 4;
-    if (c[0] > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (raise conf_thres)", c[0], max_cand);
+    if (c[0] > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (caller must resize and relaunch)", c[0], max_cand);
     int n = c[1] < cap ? c[1] : cap;
     if (n > 0) memcpy(out6_host, h_kept + (size_t)frame * MAX_DET * 6, (size_t)n * 6 * sizeof(float));
     return n;
@@ -249,6 +268,11 @@ int NmsWorkspace::run(const float *pred_dev, int n_boxes, int attrs, float conf_
                       float *out6_host, int cap, hipStream_t s) {
     launch(pred_dev, 0, 1, n_boxes, attrs, conf_thres, iou_thres, sx, sy, cap, s);
     YDS_HIP(hipStreamSynchronize(s));
+    if (needed(1) > max_cand) {                                  // more candidates than the workspace holds: grow, run again
+        resize(needed(1), frames);
+        launch(pred_dev, 0, 1, n_boxes, attrs, conf_thres, iou_thres, sx, sy, cap, s);
+        YDS_HIP(hipStreamSynchronize(s));
+    }
     return collect(0, out6_host, cap);
 }
 
@@ -261,11 +285,15 @@ int NmsWorkspace::run_merge(const float *pred_dev, int n_boxes, int attrs, float
     corner = true;
     try {
         launch(pred_dev, 0, 1, n_boxes, attrs, conf_thres, iou_thres, 1.f, 1.f, MAX_DET, s);
+        YDS_HIP(hipStreamSynchronize(s));
+        if (needed(1) > max_cand) {
+            resize(needed(1), frames);
+            launch(pred_dev, 0, 1, n_boxes, attrs, conf_thres, iou_thres, 1.f, 1.f, MAX_DET, s);
+            YDS_HIP(hipStreamSynchronize(s));
+        }
     } catch (...) { corner = false; throw; }
     corner = false;
-    YDS_HIP(hipStreamSynchronize(s));
     const int n = h_counts[0], k = h_counts[1];
-    if (n > max_cand) fail("nms: %d candidates exceed the workspace capacity %d (raise conf_thres)", n, max_cand);
     if (n > 1 && n < 3000 && (k == n || k == 1)) {
         std::vector<float> c((size_t)n * 6);
         YDS_HIP(hipMemcpy(c.data(), cand.p, c.size() * sizeof(float), hipMemcpyDeviceToHost));

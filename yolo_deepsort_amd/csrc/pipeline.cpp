@@ -29,19 +29,17 @@ public:
             for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
             nms[k].reset(new NmsWorkspace(4096, net->batch_max));
         }
-        YDS_HIP(hipStreamCreateWithFlags(&nms_stream, hipStreamNonBlocking));
     }
     ~Pipeline() {
         for (int k = 0; k < 2; ++k)
             for (hipEvent_t e : {e0[k], e1[k], e2[k], e_nms[k]}) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(nms_stream);
     }
 
     // One detector pass over a batch AND its NMS, all asynchronous on the detector stream.  Two NMS workspaces (and
     // their pinned result buffers) alternate, so that the pass of batch i+1 can be enqueued before the host has waited
     // for and read the results of batch i: the detector stream never drains between passes.
-    void launch_detector(const uint8_t *frames_dev, int h, int w, int batch) {
-        const int k = (in_flight_slot ^= 1);
+    void launch_detector(const uint8_t *frames_dev, int h, int w, int batch, int slot = -1) {
+        const int k = slot >= 0 ? slot : (in_flight_slot ^= 1);
         YDS_HIP(hipEventRecord(e0[k], net->stream));
         launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream);
         YDS_HIP(hipEventRecord(e1[k], net->stream));
@@ -67,6 +65,19 @@ public:
     // wait for the detector pass + NMS enqueued in slot k, build the detection lists
     void finish_detector(Dets &d, int k, const uint8_t *frames_dev, int batch) {
         YDS_HIP(hipEventSynchronize(e_nms[k]));
+        if (nms[k]->needed(batch) > nms[k]->max_cand) {
+            // More candidates than the workspace holds (the reference has no limit): grow it and redo this batch.  The
+            // prefetched pass of the next batch may already have overwritten the predictions, so the detector runs again
+            // after that pass has drained (its NMS results sit in the other slot's pinned buffers and stay valid).
+            // Rare slow path; bench-only logit injection is not re-selected for it.
+            YDS_HIP(hipStreamSynchronize(net->stream));
+            nms[k]->resize(nms[k]->needed(batch), nms[k]->frames);
+            const uint8_t *keep = in_flight;
+            const int keep_batch = in_flight_batch;
+            launch_detector(frames_dev, last_h, last_w, batch, k);
+            in_flight = keep; in_flight_batch = keep_batch;      // the prefetched pass (if any) is still the one in flight
+            YDS_HIP(hipEventSynchronize(e_nms[k]));
+        }
         float ms01 = 0, ms12 = 0;
         YDS_HIP(hipEventElapsedTime(&ms01, e0[k], e1[k]));
         YDS_HIP(hipEventElapsedTime(&ms12, e1[k], e2[k]));
@@ -89,8 +100,6 @@ public:
             }
             d.first[b + 1] = (int)d.payload.size();
         }
-        if ((int)d.payload.size() > reid->max_crops)
-            fail("pipeline: %d crops in one batch exceed the extractor capacity %d", (int)d.payload.size(), reid->max_crops);
     }
     // one ReID pass over the crops of the whole batch, asynchronous on the extractor's stream
     void launch_reid(Dets &d, int h, int w) {
@@ -104,6 +113,7 @@ public:
         auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
         if (batch < 1 || batch > net->batch_max) fail("pipeline: batch %d outside [1,%d]", batch, net->batch_max);
         auto t_begin = clk::now();
+        last_h = h; last_w = w;
         const bool resumed = ahead.reid_in_flight && ahead.frames == frames_dev && ahead.batch == batch;
         int next_slot = -1;
         auto launch_next = [&]() {                                  // detector (+ NMS) of the next batch goes in flight
@@ -159,8 +169,8 @@ public:
     float conf, nms_thres;
     std::vector<int32_t> class_mask;
     std::unique_ptr<NmsWorkspace> nms[2];
-    hipStream_t nms_stream = nullptr;
     int in_flight_slot = 0;
+    int last_h = 0, last_w = 0;
     Dets cur, ahead;                // this batch; the next batch when its ReID pass was started early
     DevBuf<float> feat_cur;
     int next_inject_set = -1;      // bench-only: injection set of the prefetched detector pass

@@ -101,7 +101,12 @@ void ReidNet::finalize() {
             if (down) add_conv(p + ".downsample.0", p + ".downsample.1", ci, s.cout, 1, 2, false);
         }
     }
-    // activation buffers: input, stem, pooled, then (y1, out, [shortcut]) per block
+    allocate_buffers();
+    ready = true;
+}
+
+// activation buffers: input, stem, pooled, then (y1, out, [shortcut]) per block - everything sized by max_crops
+void ReidNet::allocate_buffers() {
     in.alloc((size_t)max_crops * CROP_H * CROP_W * 4);
     feat.alloc((size_t)max_crops * EMB);
     bufs.clear();
@@ -112,12 +117,24 @@ void ReidNet::finalize() {
         if (s.down) { h /= 2; w /= 2; }
         for (int k = 0; k < 5; ++k) bufs.emplace_back((size_t)max_crops * h * w * s.cout);   // y1a, outa, sc, y1b, outb
     }
-    ready = true;
+}
+
+// The reference's extractor takes any number of crops (feature_extractor.py:53-58); the buffers grow on demand.
+// Nothing of an earlier pass may still be in flight on this stream's buffers when they are replaced.
+void ReidNet::reserve(int D) {
+    if (D <= max_crops) return;
+    YDS_HIP(hipStreamSynchronize(stream));
+    int m = max_crops;
+    while (m < D) m *= 2;
+    max_crops = m;
+    if (ready) allocate_buffers();
+    else in.alloc((size_t)max_crops * CROP_H * CROP_W * 4);
 }
 
 void ReidNet::forward(int D) {
     if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
-    if (D < 1 || D > max_crops) fail("reid: %d crops outside [1,%d]", D, max_crops);
+    if (D < 1) fail("reid: no crops");
+    reserve(D);
     const bool f16 = conv_math() == MATH_F16X3;
     auto mk = [&](DevBuf<float> &b, int h, int w, int c) {
         View v; v.p = b.p; v.n = D; v.h = h; v.w = w; v.c = c; v.ld = c;
@@ -198,7 +215,7 @@ static void crop_boxes_host(const float *tlwh, int D, int H, int W, std::vector<
 void ReidNet::embed_dev(const uint8_t *frame_dev, int h, int w, const float *tlwh_host, int D, float *out_host) {
     if (D == 0) return;
     if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
-    if (D > max_crops) fail("reid: %d crops exceed max_crops=%d", D, max_crops);
+    reserve(D);
     std::vector<int> boxes;
     crop_boxes_host(tlwh_host, D, h, w, boxes);
     boxes_dev.upload(boxes.data(), boxes.size(), stream);
@@ -206,16 +223,16 @@ void ReidNet::embed_dev(const uint8_t *frame_dev, int h, int w, const float *tlw
     View x0; x0.p = in.p; x0.n = D; x0.h = CROP_H; x0.w = CROP_W; x0.c = 4; x0.ld = 4;
     launch_crop_resize(frame_dev, h, w, boxes_dev.p, D, x0, stream);
     forward(D);
-    if (out_host) {
-        YDS_HIP(hipMemcpyAsync(out_host, feat.p, (size_t)D * EMB * sizeof(float), hipMemcpyDeviceToHost, stream));
-        YDS_HIP(hipStreamSynchronize(stream));
-    }
+    if (out_host) YDS_HIP(hipMemcpyAsync(out_host, feat.p, (size_t)D * EMB * sizeof(float), hipMemcpyDeviceToHost, stream));
+    // always complete before returning: the caller hands `feat` to the tracker, which runs on its own non-blocking
+    // stream and would otherwise read features of a pass that is still in flight
+    YDS_HIP(hipStreamSynchronize(stream));
 }
 
 void ReidNet::embed_multi_dev(const uint8_t *frames_dev, int h, int w, const float *tlwh_host, const int *frame_of, int D) {
     if (D == 0) return;
     if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
-    if (D > max_crops) fail("reid: %d crops exceed max_crops=%d", D, max_crops);
+    reserve(D);
     crop_boxes_host(tlwh_host, D, h, w, boxes_host, frame_of);
     boxes_dev.upload(boxes_host.data(), boxes_host.size(), stream);      // boxes_host outlives the copy (member)
     View x0; x0.p = in.p; x0.n = D; x0.h = CROP_H; x0.w = CROP_W; x0.c = 4; x0.ld = 4;
@@ -233,7 +250,7 @@ void ReidNet::embed_host(const uint8_t *frame_host, int h, int w, const float *t
 
 void ReidNet::preprocess_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *nchw_host) {
     if (D == 0) return;
-    if (D > max_crops) fail("reid: %d crops exceed max_crops=%d", D, max_crops);
+    reserve(D);
     if (!in.p) in.alloc((size_t)max_crops * CROP_H * CROP_W * 4);
     size_t n = (size_t)h * w * 3;
     stage_u8.ensure(n);
@@ -254,7 +271,7 @@ void ReidNet::preprocess_host(const uint8_t *frame_host, int h, int w, const flo
 void ReidNet::forward_f32_host(const float *nchw, int D, float *out_host) {
     if (D == 0) return;
     if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
-    if (D > max_crops) fail("reid: %d crops exceed max_crops=%d", D, max_crops);
+    reserve(D);
     size_t n = (size_t)D * 3 * CROP_H * CROP_W;
     stage_f32.ensure(n);
     YDS_HIP(hipMemcpyAsync(stage_f32.p, nchw, n * sizeof(float), hipMemcpyHostToDevice, stream));

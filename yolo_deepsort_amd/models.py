@@ -61,9 +61,10 @@ class Darknet:
             _lib.check(lib.yds_darknet_load_weights(self._h, blob, len(blob), self._cutoff))
 
     def set_batch_max(self, batch_max):
+        """Grow (or shrink) the activation buffers in place: the C handle, and every pipeline bound to it, stay valid."""
         if batch_max != self.batch_max:
+            _lib.check(_lib.load().yds_darknet_set_batch_max(self._h, int(batch_max)))
             self.batch_max = int(batch_max)
-            self._create()
 
     # -- reference API -------------------------------------------------
     def load_darknet_weights(self, weights_path, blob=None):
