@@ -86,7 +86,16 @@ def test_detect_plumbing_cfg1_golden():
     assert out.shape == ref.shape and ref.shape[0] > 0
     assert np.array_equal(out[:, 5], ref[:, 5])
     np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL)
-    assert det.detect(np.zeros((480, 640, 3), np.uint8)) is None or True
+    # a frame the detector finds nothing in -> None, exactly when the oracle's NMS returns None (img_detect.py:87-91)
+    from oracle.darknet import DarknetOracle
+    from oracle import nms as onms
+    from oracle.resize import resize_bilinear_u8
+    ora = DarknetOracle(cfg, 416, is_text=True)
+    ora.load_weights_array(np.frombuffer(synth.darknet_weights_blob(cfg, 0, -30.0), dtype=F32, offset=20))
+    net.load_darknet_weights(None, blob=synth.darknet_weights_blob(cfg, 0, -30.0))       # objectness bias -30: nothing passes
+    x = resize_bilinear_u8(frame, (416, 416)).astype(F32).transpose(2, 0, 1)[None] / F32(255.)
+    assert onms.soft_non_max_suppression(ora(x), 0.5, 0.4)[0] is None
+    assert det.detect(frame) is None
 
 
 def _nms_merge(pred, ct, it):
@@ -220,6 +229,23 @@ def test_reid_golden_and_oracle():
     np.testing.assert_allclose(f2, feats, rtol=1e-5, atol=1e-6)
 
 
+def test_reid_crop_resize_paths_bit_exact_and_growth():
+    """Crop geometries that reach every branch of cv2's resize: generic up/down-scaling, the exact-2x INTER_AREA route
+    (128x256 crop), the same-size copy (64x128), 1-pixel-wide crops, clipped boxes; more crops than max_crops (grows)."""
+    from oracle import reid as oreid
+    from yolo_deepsort_amd.deep_sort import Extractor
+    sd = synth.reid_state_dict(0)
+    ex = Extractor(sd, max_crops=4)
+    rng = np.random.RandomState(12)
+    frame = rng.randint(0, 256, (540, 960, 3)).astype(np.uint8)
+    tlwh = np.array([[100, 50, 128, 256], [300, 200, 64, 128], [10, 10, 1.5, 300], [500, 100, 37, 91], [-20, -30, 90, 200],
+                     [900, 400, 200, 300], [400, 300, 300, 2.2], [7.9, 8.9, 63.2, 127.2], [600, 20, 20, 40]], F32)
+    pre = ex.preprocess(frame, tlwh)
+    assert np.array_equal(pre, oreid.preprocess_crops(frame, tlwh))
+    feats = ex.embed(frame, tlwh)
+    np.testing.assert_allclose(feats, oreid.reid_forward(pre, sd), rtol=RTOL, atol=1e-5)
+
+
 def test_reid_larger_batch_vs_oracle():
     from oracle import reid as oreid
     from yolo_deepsort_amd.deep_sort import Extractor
@@ -338,6 +364,23 @@ def test_lsap_bit_exact_vs_scipy_and_oracle():
 TRACE_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
 
 
+def _check_int_rows(out, ref, st, stats):
+    """int32 output rows (deep_sort.py:85-87 truncates fp32 boxes): ids/classes exact; a box column may differ by one ONLY
+    where the pre-truncation float sits within 2e-3 of an integer (fp32 values within 1e-3 of the reference's)."""
+    assert np.array_equal(out[:, 4:], ref[:, 4:])
+    shown = (st["state"] == 2) & (st["tsu"] <= 1)
+    m = st["mean"][shown].astype(np.float64)
+    assert m.shape[0] == out.shape[0]
+    w, h = m[:, 2] * m[:, 3], m[:, 3]
+    x1, y1 = m[:, 0] - w / 2, m[:, 1] - h / 2
+    fl = np.stack([np.maximum(x1, 0), np.maximum(y1, 0), x1 + w, y1 + h], 1)
+    bad = out[:, :4] != ref[:, :4]
+    assert np.abs(out[:, :4] - ref[:, :4]).max(initial=0) <= 1
+    assert (np.abs(fl[bad] - np.rint(fl[bad])) < 2e-3).all(), fl[bad]
+    stats[0] += int(bad.sum())
+    stats[1] += bad.size
+
+
 def _run_trace(scene, g, params, drop=(), empty=()):
     from yolo_deepsort_amd.deep_sort import _TrackerHandle
     from oracle import tracker as otrk
@@ -345,6 +388,7 @@ def _run_trace(scene, g, params, drop=(), empty=()):
     trk = _TrackerHandle(params["max_dist"], params["max_iou_distance"], params["max_age"], params["n_init"], params["nn_budget"])
     ora = otrk.TrackerOracle(**params)
     n = int(g["n_frames"])
+    stats = [0, 0]
     for t in range(n):
         if f"f{t}_skipped" in g.files:
             assert t in drop
@@ -367,11 +411,12 @@ def _run_trace(scene, g, params, drop=(), empty=()):
         assert np.array_equal(st["hits"], g[f"f{t}_hits"]), t
         ref = g[f"f{t}_out"]
         assert out.shape == ref.shape == want.shape, t
-        assert np.array_equal(out[:, 4:], ref[:, 4:]), t
-        assert np.abs(out[:, :4] - ref[:, :4]).max(initial=0) <= 1, t            # int truncation of fp32 boxes
-        assert np.abs(out[:, :4] - want[:, :4]).max(initial=0) <= 1, t
+        _check_int_rows(out, ref, st, stats)                                      # vs the reference trace
+        _check_int_rows(out, want, st, [0, 0])                                    # vs the oracle
         if f"f{t}_mean" in g.files:
             np.testing.assert_allclose(st["mean"], g[f"f{t}_mean"], rtol=RTOL, atol=ATOL)
+    assert stats[1] > 0 and stats[0] / stats[1] < 2e-3, stats                     # off-by-one box columns: < 0.2 % of all ints
+    print("int32 box columns differing by one: %d of %d" % tuple(stats))
     return trk
 
 

@@ -244,12 +244,51 @@ def test_resize_front_end_bit_exact():
     from oracle.resize import resize_bilinear_u8
     net, _ = _nets(cfgs.cfg_text("yolov3-tiny"), 416, 0)
     rng = np.random.RandomState(5)
-    for h, w in ((480, 640), (1080, 1920), (416, 416), (300, 1000)):
+    # down- and up-scaling, the same-size copy, the exact-2x INTER_AREA route, extreme aspect ratios, tiny sources
+    for h, w in ((480, 640), (1080, 1920), (416, 416), (832, 832), (300, 1000), (100, 90), (2, 3), (1, 1), (833, 831)):
         frame = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
         net.forward_u8(frame, want_output=False)
         got = net.get_input(1)
         want = resize_bilinear_u8(frame, (416, 416)).astype(F32).transpose(2, 0, 1)[None] / F32(255.)
         assert np.array_equal(got, want), (h, w)
+    frame = np.zeros((480, 640, 3), np.uint8)
+    frame[::2, ::3] = 255                                   # saturated values and .5 ties
+    frame[1::2, 1::3] = 1
+    net.forward_u8(frame, want_output=False)
+    assert np.array_equal(net.get_input(1), resize_bilinear_u8(frame, (416, 416)).astype(F32).transpose(2, 0, 1)[None] / F32(255.))
+
+
+def test_batch_growth_keeps_handle_and_results():
+    """Darknet.set_batch_max re-sizes inside the C handle (a recreated handle left pipelines dangling)."""
+    net, ref = _nets(cfgs.cfg_text("yolov3-tiny", 96, 96), (96, 96), 2, -1.0, batch_max=1)
+    h0 = net._h
+    x = np.random.RandomState(3).uniform(0, 1, (5, 3, 96, 96)).astype(F32)
+    out = np.asarray(net(x))                                # grows to 5 implicitly
+    assert net._h == h0 and net.batch_max == 5
+    _close(out, ref(x))
+    net.set_batch_max(2)
+    _close(np.asarray(net(x[:2])), out[:2], 1e-5, 1e-5)
+
+
+def test_nms_workspace_grows_past_its_initial_capacity():
+    """More (box, class) candidates than the initial workspace: the reference has no cap (model_build.py:93-121)."""
+    from oracle import nms as onms
+    from yolo_deepsort_amd import _lib
+    import ctypes as C
+    rng = np.random.RandomState(8)
+    n = 9000
+    pred = np.zeros((n, 7), F32)
+    pred[:, 0] = rng.uniform(0, 3000, n); pred[:, 1] = rng.uniform(0, 3000, n)
+    pred[:, 2:4] = rng.uniform(10, 30, (n, 2))
+    pred[:, 4] = rng.uniform(0.8, 1.0, n)
+    pred[:, 5:] = rng.uniform(0.8, 1.0, (n, 2))             # both classes pass: 18000 candidates > 16384
+    out = np.zeros((300, 6), F32)
+    k = C.c_int(0)
+    _lib.check(_lib.load().yds_nms_pred(_lib.ptr(pred), n, 7, 0.5, 0.4, _lib.ptr(out), 300, C.byref(k)))
+    want = onms.soft_non_max_suppression(pred[None], 0.5, 0.4)[0]
+    assert k.value == want.shape[0] == 300
+    assert np.array_equal(out[:, 5], want[:, 5])
+    np.testing.assert_allclose(out, want, rtol=1e-6, atol=1e-6)
 
 
 def test_lane_split_matches_single_stream(monkeypatch):

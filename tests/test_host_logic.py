@@ -218,11 +218,10 @@ def test_save_darknet_weights_layout_roundtrip():
 
 
 def test_resize_restatement_geometry_vs_torch_interpolate():
-    """cv2 is absent, so the bilinear resize is 'parity unpinned' (oracle/resize.py).  Its GEOMETRY (half-pixel centres,
-    edge clamping, weights) is at least cross-checked against an independent implementation that IS in the image:
-    torch's bilinear interpolate (align_corners=False) on the same uint8 data, compared before rounding -> the rounded
-    results may differ by one grey level at most, and only where the unrounded value sits next to a .5 tie (the
-    restatement computes sample coordinates in fp32 like the device kernel, torch in fp64)."""
+    """The GEOMETRY of oracle/resize.py (half-pixel centres, edge clamping, weights) cross-checked against an independent
+    bilinear implementation that IS in the image: torch's interpolate (align_corners=False, fp64) on the same uint8 data.
+    OpenCV's 8-bit path is fixed point (11-bit weights, truncating shifts, +2 >> 2), so it sits within one grey level of
+    the real-valued result, biased slightly downwards: 12 % of the pixels differ from round(real value)."""
     import torch
     from oracle.resize import resize_bilinear_u8
     rng = np.random.RandomState(9)
@@ -231,7 +230,8 @@ def test_resize_restatement_geometry_vs_torch_interpolate():
         got = resize_bilinear_u8(img, (dw, dh)).astype(np.int32)
         t = torch.from_numpy(img).permute(2, 0, 1)[None].double()
         ref = torch.nn.functional.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
-        diff = np.abs(got - ref)
-        assert diff.max() <= 0.5 + 0.05, ((h, w), float(diff.max()))
-        assert (got != np.rint(ref)).mean() < 1e-2, ((h, w), float((got != np.rint(ref)).mean()))
+        diff = got - ref
+        assert -0.9 < diff.min() and diff.max() < 0.6, ((h, w), float(diff.min()), float(diff.max()))
+        assert np.abs(diff).mean() < 0.3
+        assert 0.05 < (got != np.rint(ref)).mean() < 0.2          # the fp32-lerp + rint definition of round 1 was NOT cv2's
         assert got.shape == (dh, dw, 3)

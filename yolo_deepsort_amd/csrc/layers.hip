@@ -312,47 +312,69 @@ void launch_inject_batch(const View &head, int batch, const float *table_dev, co
 }
 
 // ------------------------------------------------------------------------------------ bilinear u8
-// Spec (oracle/resize.py): half-pixel centres, clamped source index, fp32 lerp with every product and
-// sum rounded separately (no FMA), round-half-even to the uint8 grid.
-struct Tap { int i0, i1; float f; };
-__device__ __forceinline__ Tap axis_tap(int d, float scale, int src) {
-    float f = __fsub_rn(__fmul_rn(__fadd_rn((float)d, 0.5f), scale), 0.5f);
-    float fl = floorf(f);
+// cv2.resize(INTER_LINEAR) on 8-bit images, bit for bit (OpenCV modules/imgproc/src/resize.cpp; spec and citations in
+// oracle/resize.py): sample position in double, one rounding to float, 11-bit fixed-point weights (round half to even),
+// integer horizontal pass, vertical pass (((b0*(h0>>4))>>16) + ((b1*(h1>>4))>>16) + 2) >> 2; exact 2x down-scaling takes
+// INTER_AREA's (a+b+c+d+2)>>2, equal sizes copy.
+struct Tap { int i0, i1, a0, a1; };
+__device__ __forceinline__ double cv_scale(int dst, int src) { return __ddiv_rn(1.0, __ddiv_rn((double)dst, (double)src)); }
+template <bool X_AXIS> __device__ __forceinline__ Tap axis_tap(int d, double scale, int src) {
+    float f = __double2float_rn(__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5));
+    const float fl = floorf(f);
+    int s = (int)fl;
+    f = __fsub_rn(f, fl);
+    if (X_AXIS) {                                               // the x axis zeroes the weight when it clamps ...
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+    }
     Tap t;
-    t.i0 = (int)fl;
-    t.f = __fsub_rn(f, fl);
-    if (t.i0 < 0) { t.i0 = 0; t.f = 0.f; }
-    if (t.i0 >= src - 1) { t.i0 = src - 1; t.f = 0.f; }
-    t.i1 = min(t.i0 + 1, src - 1);
+    t.a0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+    t.a1 = (int)rintf(__fmul_rn(f, 2048.f));
+    t.i0 = min(max(s, 0), src - 1);                             // ... the y axis clips the two row indices and keeps its weights
+    t.i1 = min(max(s + 1, 0), src - 1);
     return t;
 }
-__device__ __forceinline__ float lerp2(float p00, float p01, float p10, float p11, float fx, float fy) {
-    float gx = __fsub_rn(1.f, fx), gy = __fsub_rn(1.f, fy);
-    float top = __fadd_rn(__fmul_rn(gx, p00), __fmul_rn(fx, p01));
-    float bot = __fadd_rn(__fmul_rn(gx, p10), __fmul_rn(fx, p11));
-    float v = __fadd_rn(__fmul_rn(gy, top), __fmul_rn(fy, bot));
-    return fminf(fmaxf(rintf(v), 0.f), 255.f);
+enum { RESIZE_LINEAR = 0, RESIZE_AREA2 = 1, RESIZE_COPY = 2 };
+__device__ __forceinline__ int resize_mode(int src_h, int src_w, int dst_h, int dst_w) {
+    if (src_h == dst_h && src_w == dst_w) return RESIZE_COPY;
+    if (src_h == 2 * dst_h && src_w == 2 * dst_w) return RESIZE_AREA2;
+    return RESIZE_LINEAR;
+}
+// one output pixel (3 channels) of the region whose top-left source pixel is `base` (row stride `row_bytes`)
+__device__ __forceinline__ void resize_px(const uint8_t *base, size_t row_bytes, int src_h, int src_w, int dst_h, int dst_w, int oy, int ox,
+                                          float o[3]) {
+    const int mode = resize_mode(src_h, src_w, dst_h, dst_w);
+    if (mode == RESIZE_COPY) {
+        const uint8_t *p = base + (size_t)oy * row_bytes + ox * 3;
+        o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+        return;
+    }
+    if (mode == RESIZE_AREA2) {
+        const uint8_t *p = base + (size_t)(2 * oy) * row_bytes + 2 * ox * 3, *q = p + row_bytes;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (float)(((int)p[c] + (int)p[3 + c] + (int)q[c] + (int)q[3 + c] + 2) >> 2);
+        return;
+    }
+    const Tap tx = axis_tap<true>(ox, cv_scale(dst_w, src_w), src_w), ty = axis_tap<false>(oy, cv_scale(dst_h, src_h), src_h);
+    const uint8_t *r0 = base + (size_t)ty.i0 * row_bytes, *r1 = base + (size_t)ty.i1 * row_bytes;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int h0 = (int)r0[tx.i0 * 3 + c] * tx.a0 + (int)r0[tx.i1 * 3 + c] * tx.a1;
+        const int h1 = (int)r1[tx.i0 * 3 + c] * tx.a0 + (int)r1[tx.i1 * 3 + c] * tx.a1;
+        o[c] = (float)(((((ty.a0 * (h0 >> 4)) >> 16) + ((ty.a1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff);
+    }
 }
 
 __global__ void resize_u8_kernel(const uint8_t *frames, int N, int H, int W, float *y, int Ho, int Wo, int ldy) {
-    const float sx = __fdiv_rn((float)W, (float)Wo), sy = __fdiv_rn((float)H, (float)Ho);
     const size_t total = (size_t)N * Ho * Wo;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int ox = idx % Wo;
         size_t t = idx / Wo;
         int oy = t % Ho;
         int n = t / Ho;
-        Tap tx = axis_tap(ox, sx, W), ty = axis_tap(oy, sy, H);
-        const uint8_t *img = frames + (size_t)n * H * W * 3;
-        const uint8_t *r0 = img + (size_t)ty.i0 * W * 3, *r1 = img + (size_t)ty.i1 * W * 3;
-        float o[4];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = lerp2(r0[tx.i0 * 3 + c], r0[tx.i1 * 3 + c], r1[tx.i0 * 3 + c], r1[tx.i1 * 3 + c], tx.f, ty.f);
-            o[c] = __fdiv_rn(v, 255.f);
-        }
-        o[3] = 0.f;
-        *reinterpret_cast<float4 *>(y + idx * ldy) = make_float4(o[0], o[1], o[2], o[3]);
+        float o[3];
+        resize_px(frames + (size_t)n * H * W * 3, (size_t)W * 3, H, W, Ho, Wo, oy, ox, o);
+        *reinterpret_cast<float4 *>(y + idx * ldy) = make_float4(__fdiv_rn(o[0], 255.f), __fdiv_rn(o[1], 255.f), __fdiv_rn(o[2], 255.f), 0.f);
     }
 }
 
@@ -372,17 +394,9 @@ __global__ void tile_resize_kernel(const uint8_t *frame, int W, const int *tiles
         int oy = t % Ho;
         int n = t / Ho;
         const int x0 = tiles[n * 4 + 0], y0 = tiles[n * 4 + 1], th = tiles[n * 4 + 2], tw = tiles[n * 4 + 3];
-        const float sx = __fdiv_rn((float)tw, (float)Wo), sy = __fdiv_rn((float)th, (float)Ho);
-        Tap tx = axis_tap(ox, sx, tw), ty = axis_tap(oy, sy, th);
-        const uint8_t *r0 = frame + ((size_t)(y0 + ty.i0) * W + x0) * 3, *r1 = frame + ((size_t)(y0 + ty.i1) * W + x0) * 3;
-        float o[4];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = lerp2(r0[tx.i0 * 3 + c], r0[tx.i1 * 3 + c], r1[tx.i0 * 3 + c], r1[tx.i1 * 3 + c], tx.f, ty.f);
-            o[c] = __fdiv_rn(v, 255.f);
-        }
-        o[3] = 0.f;
-        *reinterpret_cast<float4 *>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        float o[3];
+        resize_px(frame + ((size_t)y0 * W + x0) * 3, (size_t)W * 3, th, tw, Ho, Wo, oy, ox, o);
+        *reinterpret_cast<float4 *>(y + idx * 4) = make_float4(__fdiv_rn(o[0], 255.f), __fdiv_rn(o[1], 255.f), __fdiv_rn(o[2], 255.f), 0.f);
     }
 }
 
@@ -425,17 +439,12 @@ __global__ void crop_resize_kernel(const uint8_t *frames, int H, int W, const in
         int d = t / Ho;
         int x1 = boxes[d * 5], y1 = boxes[d * 5 + 1], cw = boxes[d * 5 + 2] - x1, ch = boxes[d * 5 + 3] - y1;
         const uint8_t *frame = frames + (size_t)boxes[d * 5 + 4] * H * W * 3;
-        Tap tx = axis_tap(ox, __fdiv_rn((float)cw, (float)Wo), cw), ty = axis_tap(oy, __fdiv_rn((float)ch, (float)Ho), ch);
-        const uint8_t *r0 = frame + ((size_t)(y1 + ty.i0) * W + x1) * 3, *r1 = frame + ((size_t)(y1 + ty.i1) * W + x1) * 3;
         const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
-        float o[4];
+        float o[3];
+        resize_px(frame + ((size_t)y1 * W + x1) * 3, (size_t)W * 3, ch, cw, Ho, Wo, oy, ox, o);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = lerp2(r0[tx.i0 * 3 + c], r0[tx.i1 * 3 + c], r1[tx.i0 * 3 + c], r1[tx.i1 * 3 + c], tx.f, ty.f);
-            o[c] = __fdiv_rn(__fsub_rn(__fdiv_rn(v, 255.f), mean[c]), stdv[c]);
-        }
-        o[3] = 0.f;
-        *reinterpret_cast<float4 *>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        for (int c = 0; c < 3; ++c) o[c] = __fdiv_rn(__fsub_rn(__fdiv_rn(o[c], 255.f), mean[c]), stdv[c]);
+        *reinterpret_cast<float4 *>(y + idx * 4) = make_float4(o[0], o[1], o[2], 0.f);
     }
 }
 
