@@ -152,12 +152,27 @@ int yds_reid_forward_f32(yds_reid *, const float *nchw_host, int D, float *out_h
  *   dbg_matches (optional) receives (track_index, det_index) pairs in reference order.
  */
 yds_trk *yds_tracker_create(double max_dist, double max_iou_distance, int max_age, int n_init, int nn_budget);
+/* NearestNeighborDistanceMetric(metric, matching_threshold, budget) deep_sort/sort/nn_matching.py:103-137:
+ * metric 0 = "cosine", 1 = "euclidean" (_nn_euclidean_distance :56-74: min over the track's gallery of the squared
+ * distance, clamped at 0; the reference's own distance() passes it a third argument and raises - see DESIGN.md);
+ * nn_budget <= 0 = budget None: galleries are unbounded (:152-154). */
+yds_trk *yds_tracker_create_ex(double max_dist, double max_iou_distance, int max_age, int n_init, int nn_budget, int metric);
 void yds_tracker_destroy(yds_trk *);
 int yds_tracker_step(yds_trk *, const float *tlwh_host, const float *feats_host, const float *payload_host,
                      int D, int32_t *out6_host, int cap, int *m_out,
                      int32_t *dbg_matches_host, int dbg_cap, int *n_matches);
 int yds_tracker_step_dev(yds_trk *, const float *tlwh_host, const float *feats_dev, const float *payload_host,
                          int D, int32_t *out6_host, int cap, int *m_out);
+/* as yds_tracker_step / _dev, with a row selection: detection d uses feature row feat_rows[d] (NULL = d).  This is how
+ * DeepSort.update hands over the survivors of the tracker-side NMS (deep_sort.py:52-57: features are extracted for all
+ * boxes first, then `detections = [detections[i] for i in indices]`). */
+int yds_tracker_step_sel(yds_trk *, const float *tlwh_host, const float *feats, int feats_on_device, const int32_t *feat_rows_host,
+                         const float *payload_host, int D, int32_t *out6_host, int cap, int *m_out,
+                         int32_t *dbg_matches_host, int dbg_cap, int *n_matches);
+/* non_max_suppression(boxes, max_bbox_overlap, scores) deep_sort/sort/preprocessing.py:6-73: tlwh boxes, float64, +1 pixel
+ * convention, overlap = inter / area(other); order_host = np.argsort(scores) (walked from its end); pick_host receives the
+ * kept detection indices in pick order. */
+int yds_tracker_nms(const float *tlwh_host, const int32_t *order_host, int D, double max_overlap, int32_t *pick_host, int *n_pick);
 int yds_tracker_num_tracks(const yds_trk *);
 int yds_tracker_get_state(yds_trk *, int32_t *ids, int32_t *state, int32_t *tsu, int32_t *hits,
                           float *mean8, float *cov64, int cap, int *T);
@@ -172,6 +187,8 @@ int yds_kalman_gating(const float *mean_host, const float *cov_host, int T, cons
 int yds_iou_cost(const float *track_tlwh_host, int T, const float *det_tlwh_host, int D, float *out_TxD_host);
 int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T,
                         const float *feats_host, int D, int dim, float *out_TxD_host);
+int yds_euclidean_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T,
+                           const float *feats_host, int D, int dim, float *out_TxD_host);   /* nn_matching.py:4-27,56-74 per track */
 
 /* ---- pipeline: VideoDetector.detect hot glue (video_detect.py:134-157) ----------------------
  * One stream of frames: detector over `batch` consecutive frames, NMS of every frame, class mask,

@@ -7,6 +7,7 @@ yolo_deepsort_amd.synth) and the reference's outputs.  Nothing from the
 reference tree is copied; it is imported through oracle/ref_harness.py.
 """
 
+import importlib
 import json
 import os
 import sys
@@ -418,11 +419,30 @@ class _FakeExtractor:
         return torch.from_numpy(self.next)
 
 
-def run_reference_trace(ns, scene, n_frames, params, drop_frames=(), empty_frames=()):
-    """Drive the real DeepSort.update frame by frame; record everything observable."""
+def run_reference_trace(ns, scene, n_frames, params, drop_frames=(), empty_frames=(), metric=None, boxes_of=None):
+    """Drive the real DeepSort.update frame by frame; record everything observable.
+    metric="euclidean": the reference's DeepSort hard-wires "cosine" (deep_sort.py:34) and its euclidean helper is called
+    with one argument too many (nn_matching.py:56 vs :187 -> TypeError), so the trace is taken with the metric object
+    swapped for NearestNeighborDistanceMetric("euclidean", ...) whose _metric applies the reference's OWN
+    _nn_euclidean_distance per track segment - a harness-side adapter, flagged in the fixture name."""
     import torch
     ex = _FakeExtractor()
     ds = ns.deep_sort.DeepSort(ex, use_cuda=False, **params)
+    if metric == "euclidean":
+        nn = sys.modules[type(ds.tracker.metric).__module__]
+        m = nn.NearestNeighborDistanceMetric("euclidean", params["max_dist"], params["nn_budget"])
+        m._metric = lambda x, y, bp: torch.stack([nn._nn_euclidean_distance(x[bp[i]:bp[i + 1]], y) for i in range(len(bp) - 1)], 0)
+        ds.tracker.metric = m
+    pre = sys.modules.get(type(ds).__module__)
+    orders = []
+    if params.get("nms_max_overlap", 1.0) != 1:
+        # record the np.argsort(scores) the reference observed (a constant vector: numpy's choice, platform dependent)
+        orig_nms = pre.non_max_suppression
+
+        def nms_spy(boxes, thr, scores=None):
+            orders.append(np.argsort(scores).astype(np.int32))
+            return orig_nms(boxes, thr, scores)
+        pre.non_max_suppression = nms_spy
     rec = []
     orig_match = ds.tracker._match
     last = {}
@@ -437,16 +457,18 @@ def run_reference_trace(ns, scene, n_frames, params, drop_frames=(), empty_frame
         if t in drop_frames:            # detector returned None: tracker not called (video_detect.py:137)
             rec.append(None)
             continue
-        ids, tlwh = scene.boxes(t)
-        feats = scene.features(t)
+        ids, tlwh = scene.boxes(t) if boxes_of is None else boxes_of(t)
+        feats = scene.features(t) if boxes_of is None else boxes_of(t, feats=True)
         if t in empty_frames:           # class mask emptied the list: called with D = 0
             tlwh, feats, ids = tlwh[:0], feats[:0], ids[:0]
         ex.next = feats
         payload = torch.from_numpy((ids % 3 * 2).astype(F32))
+        n_orders = len(orders)
         out = ds.update(torch.from_numpy(tlwh), torch.ones(len(tlwh)), frame, payload)
         m, ut, ud = last["m"]
         tr = ds.tracker.tracks
-        rec.append(dict(
+        extra = {"nms_order": orders[-1]} if len(orders) > n_orders else {}
+        rec.append(dict(extra, 
             out=np.array(out, dtype=np.int32).reshape(-1, 6),
             matches=np.array(m, dtype=np.int32).reshape(-1, 2),
             um_t=np.array(sorted(ut), dtype=np.int32), um_d=np.array(ud, dtype=np.int32),
@@ -536,7 +558,56 @@ def gen_tiled(ns):
     _save("tiled_detect", **arrays)
 
 
-ALL = dict(tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
+def gen_track_options(ns):
+    """NearestNeighborDistanceMetric / DeepSort options beside the demo's defaults: budget=None
+    (nn_matching.py:152-154), tracker-side NMS (preprocessing.py:6-73 via deep_sort.py:52-57), the euclidean helpers
+    (nn_matching.py:4-27,56-74)."""
+    import torch
+    nn = importlib.import_module("deep_sort.sort.nn_matching")
+    pre = importlib.import_module("deep_sort.sort.preprocessing")
+    # -- unbounded gallery
+    unb = dict(TRACE_PARAMS, nn_budget=None)
+    rec = run_reference_trace(ns, synth.PersonScene(10, seed=5, occlude_frac=0.3), 80, unb)
+    _save("track_trace_budget_none", **_pack_trace(rec))
+    # -- tracker-side NMS: duplicated (jittered) boxes make it bite; > 16 detections so that argsort is not trivially sorted
+    scene = synth.PersonScene(14, seed=6, occlude_frac=0.1)
+    rng = np.random.RandomState(3)
+    jit = rng.uniform(-4, 4, (200, 14, 4)).astype(F32)
+
+    def boxes_of(t, feats=False):
+        ids, tlwh = scene.boxes(t)
+        dup = (tlwh + jit[t, :len(ids)]).astype(F32)
+        if feats:
+            f = scene.features(t)
+            return np.concatenate([f, f], 0)
+        return np.concatenate([ids, ids]), np.concatenate([tlwh, dup], 0)
+    rec = run_reference_trace(ns, scene, 40, dict(TRACE_PARAMS, nms_max_overlap=0.6), boxes_of=boxes_of)
+    assert any("nms_order" in r for r in rec)
+    arrays = _pack_trace(rec)
+    arrays["jitter"] = jit[:40]
+    _save("track_trace_nms06", **arrays)
+    # -- euclidean metric through the adapter described in run_reference_trace (max_dist on squared distances of unit vectors)
+    rec = run_reference_trace(ns, synth.PersonScene(20, seed=7, occlude_frac=0.2), 50, dict(TRACE_PARAMS, max_dist=0.6), metric="euclidean")
+    _save("track_trace_euclidean_adapter", **_pack_trace(rec))
+    # -- unit vectors for the helpers themselves
+    arrays = {}
+    g = rng.randn(37, 512).astype(F32)
+    f = rng.randn(11, 512).astype(F32)
+    f[3] = g[5]                                                     # an exact zero distance (clamp at 0)
+    seg = np.array([0, 1, 6, 20, 37], np.int32)
+    arrays.update(euc_gallery=g, euc_feats=f, euc_seg=seg,
+                  euc_out=torch.stack([nn._nn_euclidean_distance(torch.from_numpy(g[seg[i]:seg[i + 1]]), torch.from_numpy(f)) for i in range(4)], 0).numpy(),
+                  pdist=nn._pdist(torch.from_numpy(g[:6]), torch.from_numpy(f)).numpy())
+    boxes = np.concatenate([rng.uniform(0, 300, (40, 2)), rng.uniform(20, 120, (40, 2))], 1).astype(F32)
+    for k, (thr, scores) in enumerate([(0.5, np.ones(40)), (0.3, rng.uniform(0, 1, 40)), (0.9, np.ones(40)), (0.0, np.ones(40))]):
+        arrays[f"nms{k}_order"] = np.argsort(scores).astype(np.int32)
+        arrays[f"nms{k}_thr"] = np.array(thr)
+        arrays[f"nms{k}_pick"] = np.array(pre.non_max_suppression(boxes, thr, scores), np.int32)
+    arrays["nms_boxes"] = boxes
+    _save("track_options_units", **arrays)
+
+
+ALL = dict(options=gen_track_options, tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
            nms=gen_nms, plumbing=gen_detect_plumbing, reid=gen_reid, kalman=gen_kalman,
            traces=gen_track_traces)
 

@@ -30,6 +30,9 @@ def _nms_stub(boxes, scores, iou_threshold):
 
 def install_shims():
     import torch
+    if not hasattr(np, "float"):
+        # deep_sort/sort/preprocessing.py:41 uses the alias numpy removed in 1.24 (`boxes.astype(np.float)` = float64)
+        np.float = float
     if not hasattr(torch, "solve") or getattr(torch.solve, "_yds_shim", False) is False:
         def solve(B, A):
             return torch.linalg.solve(A, B), None

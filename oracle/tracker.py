@@ -104,6 +104,34 @@ def cosine_distance(a, b):
     return (F32(1.) - a.astype(F32) @ b.astype(F32).T).astype(F32)
 
 
+def euclidean_min_distance(samples, feats):
+    """nn_matching.py:4-27,56-74: min over `samples` rows of sum((a - b)^2), clamped at 0 -> [len(feats)]."""
+    d = ((samples[:, None, :] - feats[None, :, :]).astype(F32) ** 2).sum(-1, dtype=F32)
+    return np.maximum(d.min(axis=0), F32(0)).astype(F32)
+
+
+def tracker_nms(tlwh, max_bbox_overlap, order):
+    """deep_sort/sort/preprocessing.py:6-73 with scores given (order = np.argsort(scores), decided by numpy)."""
+    if len(tlwh) == 0:
+        return []
+    boxes = np.asarray(tlwh).astype(np.float64)
+    x1, y1 = boxes[:, 0], boxes[:, 1]
+    x2, y2 = boxes[:, 2] + boxes[:, 0], boxes[:, 3] + boxes[:, 1]
+    area = (x2 - x1 + 1) * (y2 - y1 + 1)
+    idxs = np.asarray(order).copy()
+    pick = []
+    while len(idxs) > 0:
+        last = len(idxs) - 1
+        i = idxs[last]
+        pick.append(int(i))
+        rest = idxs[:last]
+        w = np.maximum(0, np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + 1)
+        h = np.maximum(0, np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + 1)
+        overlap = (w * h) / area[rest]
+        idxs = np.delete(idxs, np.concatenate(([last], np.where(overlap > max_bbox_overlap)[0])))
+    return pick
+
+
 def iou_matrix(bbox, cand):
     """iou_matching.py:5-41 (asymmetric +1 in the intersection only)."""
     b = bbox[:, None, :]
@@ -163,7 +191,11 @@ def min_cost_matching(cost, max_distance, track_indices, detection_indices):
 class TrackerOracle:
     """DeepSort.update minus the ReID extractor: takes features directly."""
 
-    def __init__(self, max_dist=0.2, max_iou_distance=0.7, max_age=70, n_init=3, nn_budget=100):
+    def __init__(self, max_dist=0.2, max_iou_distance=0.7, max_age=70, n_init=3, nn_budget=100, metric="cosine", nms_max_overlap=1.0):
+        if metric not in ("cosine", "euclidean"):
+            raise ValueError("Invalid metric; must be either 'euclidean' or 'cosine'")
+        self.metric, self.nms_max_overlap = metric, nms_max_overlap
+        self.nms_order = None                      # test hook: the np.argsort(scores) the reference run observed
         self.max_dist, self.max_iou_distance = max_dist, max_iou_distance
         self.max_age, self.n_init, self.budget = max_age, n_init, nn_budget
         self.tracks = []
@@ -198,8 +230,14 @@ class TrackerOracle:
                 s = self.samples[self.tracks[i].track_id]
                 samples += s
                 bp.append(bp[-1] + len(s))
-            dist = cosine_distance(np.stack(samples, 0), feats[det_idx])
-            cost = np.stack([dist[bp[k]:bp[k + 1]].min(axis=0) for k in range(len(bp) - 1)], 0)
+            if self.metric == "euclidean":
+                # the reference's distance() hands _nn_euclidean_distance a third argument and raises (nn_matching.py:56,187);
+                # the evident intent - the helper applied per track segment - is what is restated
+                g = np.stack(samples, 0)
+                cost = np.stack([euclidean_min_distance(g[bp[k]:bp[k + 1]], feats[det_idx]) for k in range(len(bp) - 1)], 0)
+            else:
+                dist = cosine_distance(np.stack(samples, 0), feats[det_idx])
+                cost = np.stack([dist[bp[k]:bp[k + 1]].min(axis=0) for k in range(len(bp) - 1)], 0)
             xyah = tlwh_to_xyah(tlwh[det_idx])
             means = np.concatenate([self.tracks[i].mean for i in confirmed], 0)
             covs = np.concatenate([self.tracks[i].cov for i in confirmed], 0)
@@ -227,6 +265,11 @@ class TrackerOracle:
         feats = np.asarray(feats, dtype=F32).reshape(tlwh.shape[0], -1) if tlwh.shape[0] else np.zeros((0, 0), F32)
         payload = np.asarray(payload, dtype=F32).reshape(-1)
         self.debug = {}
+        if self.nms_max_overlap != 1:                            # deep_sort.py:52-57 (confidence is 1 for every detection)
+            order = self.nms_order if self.nms_order is not None else np.argsort(np.ones(len(tlwh), dtype=np.float64))
+            keep = tracker_nms(tlwh, self.nms_max_overlap, order)
+            tlwh, feats, payload = tlwh[keep], feats[keep], payload[keep]
+            self.debug["nms_keep"] = keep
         self._predict()
         matches, um_t, um_d = self._match(tlwh, feats)
         self.debug.update(matches=list(matches), unmatched_tracks=sorted(um_t), unmatched_detections=list(um_d))

@@ -381,11 +381,12 @@ def _check_int_rows(out, ref, st, stats):
     stats[1] += bad.size
 
 
-def _run_trace(scene, g, params, drop=(), empty=()):
+def _run_trace(scene, g, params, drop=(), empty=(), frame_of=None):
     from yolo_deepsort_amd.deep_sort import _TrackerHandle
     from oracle import tracker as otrk
     _lib()
-    trk = _TrackerHandle(params["max_dist"], params["max_iou_distance"], params["max_age"], params["n_init"], params["nn_budget"])
+    trk = _TrackerHandle(params["max_dist"], params["max_iou_distance"], params["max_age"], params["n_init"], params["nn_budget"],
+                         params.get("metric", "cosine"))
     ora = otrk.TrackerOracle(**params)
     n = int(g["n_frames"])
     stats = [0, 0]
@@ -393,8 +394,11 @@ def _run_trace(scene, g, params, drop=(), empty=()):
         if f"f{t}_skipped" in g.files:
             assert t in drop
             continue
-        ids, tlwh = scene.boxes(t)
-        feats = scene.features(t)
+        if frame_of is not None:
+            ids, tlwh, feats = frame_of(t)
+        else:
+            ids, tlwh = scene.boxes(t)
+            feats = scene.features(t)
         if t in empty:
             tlwh, feats, ids = tlwh[:0], feats[:0], ids[:0]
         payload = (ids % 3 * 2).astype(F32)
@@ -433,3 +437,70 @@ def test_track_trace_short_max_age_golden():
 def test_track_trace_crowd_200x150_golden():
     """BASELINE cfg5 association load: 200 live tracks, 150 detections per frame."""
     _run_trace(synth.PersonScene(200, seed=0, n_visible=150), golden("track_trace_200x150"), TRACE_PARAMS)
+
+
+@pytest.mark.parametrize("name", ["track_trace_budget_none", "track_trace_euclidean_adapter"])
+def test_tracker_metric_options_vs_reference_traces(name):
+    """nn_budget=None (unbounded galleries: the per-track row capacity doubles past 32 and 64) and the euclidean metric."""
+    from conftest import option_trace
+    g, params, frame_of = option_trace(name)
+    _run_trace(None, g, params, frame_of=frame_of)
+
+
+def test_tracker_side_nms_trace_and_units():
+    """DeepSort(nms_max_overlap=0.6).update: features for all boxes, preprocessing.non_max_suppression, survivors in pick
+    order (deep_sort.py:46-57).  The constant-score argsort is numpy's choice in the reference; the trace pins the order
+    the reference run observed."""
+    from conftest import option_trace
+    from yolo_deepsort_amd.deep_sort import DeepSort
+    L = _lib()
+    lib = L.load()
+    g = golden("track_options_units")
+    boxes = np.ascontiguousarray(g["nms_boxes"], dtype=F32)
+    for k in range(4):
+        order = np.ascontiguousarray(g[f"nms{k}_order"], dtype=np.int32)
+        pick = np.zeros(len(boxes), np.int32)
+        n = C.c_int(0)
+        L.check(lib.yds_tracker_nms(L.ptr(boxes), L.ptr(order), len(boxes), float(g[f"nms{k}_thr"]), L.ptr(pick), C.byref(n)))
+        assert pick[:n.value].tolist() == g[f"nms{k}_pick"].tolist(), k
+    # euclidean helper per track segment
+    seg = np.ascontiguousarray(g["euc_seg"], dtype=np.int32)
+    gal, f = np.ascontiguousarray(g["euc_gallery"]), np.ascontiguousarray(g["euc_feats"])
+    out = np.zeros((len(seg) - 1, len(f)), F32)
+    L.check(lib.yds_euclidean_min_cost(L.ptr(gal), L.ptr(seg), len(seg) - 1, L.ptr(f), len(f), 512, L.ptr(out)))
+    np.testing.assert_allclose(out, g["euc_out"], rtol=1e-5, atol=1e-4)
+    assert out[1, 3] == 0.0
+    # whole DeepSort.update with a callable extractor that returns the scripted features
+    g, params, frame_of = option_trace("track_trace_nms06")
+    state = {}
+
+    def extractor(crops):
+        assert len(crops) == len(state["feats"])
+        return state["feats"]
+    ds = DeepSort(extractor, use_cuda=True, **params)
+    frame = np.zeros((1080, 1920, 3), np.uint8)
+    for t in range(int(g["n_frames"])):
+        ids, tlwh, feats = frame_of(t)
+        state["feats"] = feats
+        order = g[f"f{t}_nms_order"]
+        ds._nms_keep = (lambda boxes, _o=order, _ds=ds: _keep_with_order(_ds, boxes, _o))
+        out = ds.update(tlwh, np.ones(len(ids)), frame, (ids % 3 * 2).astype(F32))
+        out = np.array(out, np.int32).reshape(-1, 6)
+        ref = g[f"f{t}_out"]
+        st = ds.tracker.state()
+        assert np.array_equal(st["ids"], g[f"f{t}_ids"]) and np.array_equal(st["state"], g[f"f{t}_state"]), t
+        assert out.shape == ref.shape and np.array_equal(out[:, 4:], ref[:, 4:]), t
+        assert np.abs(out[:, :4] - ref[:, :4]).max(initial=0) <= 1, t
+    with pytest.raises(ValueError):
+        DeepSort(extractor, metric="manhattan")
+
+
+def _keep_with_order(ds, tlwh, order):
+    import ctypes as C
+    from yolo_deepsort_amd import _lib as L
+    d = tlwh.shape[0]
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    pick = np.zeros(d, np.int32)
+    n = C.c_int(0)
+    L.check(L.load().yds_tracker_nms(L.ptr(tlwh), L.ptr(order), d, float(ds.nms_max_overlap), L.ptr(pick), C.byref(n)))
+    return pick[:n.value].copy()

@@ -90,17 +90,22 @@ def test_lsap_matches_scipy_tie_heavy():
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1)
 
 
-def _run_trace(scene, g, params, drop=(), empty=()):
+def _run_trace(scene, g, params, drop=(), empty=(), frame_of=None):
     trk = otrk.TrackerOracle(**params)
     n = int(g["n_frames"])
     for t in range(n):
         if f"f{t}_skipped" in g.files:
             assert t in drop
             continue
-        ids, tlwh = scene.boxes(t)
-        feats = scene.features(t)
+        if frame_of is not None:
+            ids, tlwh, feats = frame_of(t)
+        else:
+            ids, tlwh = scene.boxes(t)
+            feats = scene.features(t)
         if t in empty:
             tlwh, feats, ids = tlwh[:0], feats[:0], ids[:0]
+        if f"f{t}_nms_order" in g.files:
+            trk.nms_order = g[f"f{t}_nms_order"]          # the constant-vector argsort the reference run observed
         out = trk.update(tlwh, feats, (ids % 3 * 2).astype(F32))
         out = np.array(out, dtype=np.int32).reshape(-1, 6)
         st = trk.state()
@@ -136,3 +141,27 @@ def test_track_trace_short_max_age():
 
 def test_track_trace_crowd_200x150():
     _run_trace(synth.PersonScene(200, seed=0, n_visible=150), golden("track_trace_200x150"), TRACE_PARAMS)
+
+
+@pytest.mark.parametrize("name", ["track_trace_budget_none", "track_trace_nms06", "track_trace_euclidean_adapter"])
+def test_track_option_traces(name):
+    """budget=None, tracker-side NMS and the euclidean metric against reference-generated traces."""
+    from conftest import option_trace
+    g, params, frame_of = option_trace(name)
+    trk = _run_trace(None, g, params, frame_of=frame_of)
+    if name == "track_trace_budget_none":
+        assert max(len(v) for v in trk.samples.values()) > 30          # galleries really grew past the demo's budget
+    if name == "track_trace_nms06":
+        assert any(len(g[f"f{t}_matches"]) + len(g[f"f{t}_um_d"]) < 2 * len(frame_of(t)[0]) for t in range(int(g["n_frames"])))
+
+
+def test_option_units_vs_reference_vectors():
+    g = golden("track_options_units")
+    seg = g["euc_seg"]
+    got = np.stack([otrk.euclidean_min_distance(g["euc_gallery"][seg[i]:seg[i + 1]], g["euc_feats"]) for i in range(len(seg) - 1)], 0)
+    np.testing.assert_allclose(got, g["euc_out"], rtol=1e-5, atol=1e-4)
+    assert got[1, 3] == 0.0                                              # the planted exact match (clamp at 0)
+    for k in range(4):
+        assert otrk.tracker_nms(g["nms_boxes"], float(g[f"nms{k}_thr"]), g[f"nms{k}_order"]) == g[f"nms{k}_pick"].tolist(), k
+    with pytest.raises(ValueError):
+        otrk.TrackerOracle(metric="manhattan")

@@ -80,6 +80,10 @@ SIGNATURES = {
     "yds_reid_preprocess": (_I, [_P, _P, _I, _I, _P, _I, _P]),
     "yds_reid_forward_f32": (_I, [_P, _P, _I, _P]),
     "yds_tracker_create": (_P, [C.c_double, C.c_double, _I, _I, _I]),
+    "yds_tracker_create_ex": (_P, [C.c_double, C.c_double, _I, _I, _I, _I]),
+    "yds_tracker_step_sel": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P]),
+    "yds_tracker_nms": (_I, [_P, _P, _I, C.c_double, _P, _P]),
+    "yds_euclidean_min_cost": (_I, [_P, _P, _I, _P, _I, _I, _P]),
     "yds_tracker_destroy": (None, [_P]),
     "yds_tracker_step": (_I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _P]),
     "yds_tracker_step_dev": (_I, [_P, _P, _P, _P, _I, _P, _I, _P]),

@@ -183,8 +183,8 @@ __global__ void gating_kernel(const float *mean, const float *cov, const int *sl
 // (normalize_rows_kernel) - the same division the reference repeats on every call.  One workgroup per (track,
 // 16-detection slab): the slab and 16 gallery rows at a time sit in LDS (rows padded by one float: conflict free),
 // thread (r, d) owns one dot product per chunk and keeps a running minimum.
-__global__ void normalize_rows_kernel(const float *src, const int *src_idx, float *dst, int n) {
-    // one wave per row: dst[row] = src[idx[row]] / ||src[idx[row]]||
+__global__ void normalize_rows_kernel(const float *src, const int *src_idx, float *dst, int n, int normalise) {
+    // one wave per row: dst[row] = src[idx[row]] / ||src[idx[row]]||  (plain gather when !normalise: euclidean metric)
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= n) return;
     const float *f = src + (size_t)(src_idx ? src_idx[row] : row) * EMB;
@@ -192,14 +192,14 @@ __global__ void normalize_rows_kernel(const float *src, const int *src_idx, floa
 #pragma unroll
     for (int k = 0; k < EMB / 64; ++k) { v[k] = f[lane + 64 * k]; ss += v[k] * v[k]; }
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const float nrm = sqrtf(ss);
+    const float nrm = normalise ? sqrtf(ss) : 1.f;
 #pragma unroll
     for (int k = 0; k < EMB / 64; ++k) dst[(size_t)row * EMB + lane + 64 * k] = v[k] / nrm;
 }
 
 __global__ __launch_bounds__(256) void appearance_cost_kernel(const float *gallery_n, const int *slots, const int *n_rows, int budget,
                                                              const float *feats_n, int D, const float *mean, const float *cov,
-                                                             const float *tlwh, float max_dist, float flood, int do_gate, float *cost) {
+                                                             const float *tlwh, float max_dist, float flood, int do_gate, int euclid, float *cost) {
     __shared__ float fs[16][EMB + 1], gs[16][EMB + 1];
     __shared__ float best[16][17];
     const int t = blockIdx.x, d0 = blockIdx.y * 16;
@@ -223,9 +223,15 @@ __global__ __launch_bounds__(256) void appearance_cost_kernel(const float *galle
         __syncthreads();
         if (g0 + r < rows) {
             float dot = 0.f;
+            if (euclid) {                                        // _pdist nn_matching.py:4-27: sum (a - b)^2
 #pragma unroll 8
-            for (int k = 0; k < EMB; ++k) dot += gs[r][k] * fs[d][k];
-            run_min = fminf(run_min, 1.f - dot);
+                for (int k = 0; k < EMB; ++k) { const float df = gs[r][k] - fs[d][k]; dot += df * df; }
+                run_min = fminf(run_min, dot);
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < EMB; ++k) dot += gs[r][k] * fs[d][k];
+                run_min = fminf(run_min, 1.f - dot);
+            }
         }
     }
     best[r][d] = run_min;
@@ -234,6 +240,7 @@ __global__ __launch_bounds__(256) void appearance_cost_kernel(const float *galle
         float c = INFINITY;
 #pragma unroll
         for (int q = 0; q < 16; ++q) c = fminf(c, best[q][threadIdx.x]);
+        if (euclid) c = fmaxf(c, 0.f);                           // torch.clamp(min=0) nn_matching.py:74
         const int dd = d0 + threadIdx.x;
         if (do_gate) {
             float z[4];
@@ -417,8 +424,44 @@ __global__ void output_kernel(const float *mean, const int *slots, const int *id
     o[0] = (int)x; o[1] = (int)y; o[2] = (int)x2; o[3] = (int)y2; o[4] = ids[t]; o[5] = (int)payload[t];
 }
 
+// ------------------------------------------------------------------------------- tracker-side NMS
+// deep_sort/sort/preprocessing.py:6-73 (gate: deep_sort.py:52-57): greedy suppression in float64 over tlwh boxes with
+// the +1 pixel convention; walks `order` (= np.argsort(scores)) from its END, suppresses j when
+// inter(i, j) / area(j) > max_overlap.  pick[] receives the surviving detection indices in pick order.
+__global__ __launch_bounds__(256) void tracker_nms_kernel(const float *tlwh, const int *order, int n, double max_overlap, int *pick, int *n_pick) {
+    extern __shared__ int alive[];                               // alive[k] for position k of `order`
+    __shared__ int cur, count;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) alive[k] = 1;
+    if (threadIdx.x == 0) { cur = n - 1; count = 0; }
+    __syncthreads();
+    while (true) {
+        const int last = cur;
+        if (last < 0) break;
+        const int i = order[last];
+        const double ix1 = tlwh[i * 4], iy1 = tlwh[i * 4 + 1], ix2 = (double)tlwh[i * 4 + 2] + ix1, iy2 = (double)tlwh[i * 4 + 3] + iy1;
+        for (int k = threadIdx.x; k < last; k += blockDim.x) {
+            if (!alive[k]) continue;
+            const int j = order[k];
+            const double x1 = tlwh[j * 4], y1 = tlwh[j * 4 + 1], x2 = (double)tlwh[j * 4 + 2] + x1, y2 = (double)tlwh[j * 4 + 3] + y1;
+            const double area = (x2 - x1 + 1.0) * (y2 - y1 + 1.0);
+            const double w = fmax(0.0, fmin(ix2, x2) - fmax(ix1, x1) + 1.0), h = fmax(0.0, fmin(iy2, y2) - fmax(iy1, y1) + 1.0);
+            if ((w * h) / area > max_overlap) alive[k] = 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            pick[count++] = i;
+            int k = last - 1;
+            while (k >= 0 && !alive[k]) --k;
+            cur = k;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_pick = count;
+}
+
 // ============================================================================================ host
 enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
+enum { METRIC_COSINE = 0, METRIC_EUCLIDEAN = 1 };
 
 struct Track {
     int slot, id, hits = 1, age = 1, tsu = 0, state = TENTATIVE;
@@ -428,9 +471,12 @@ struct Track {
 
 class Tracker : public TrackerIface {
 public:
-    Tracker(double max_dist, double max_iou, int max_age, int n_init, int budget)
-        : max_dist(max_dist), max_iou(max_iou), max_age(max_age), n_init(n_init), budget(budget) {
-        if (budget < 1) fail("tracker: nn_budget must be >= 1 (unbounded galleries are not supported)");
+    // budget <= 0: nn_budget=None, every track keeps all its features (nn_matching.py:152-154) - the per-track row
+    // capacity `budget` then doubles whenever a gallery fills up; metric: cosine | euclidean (nn_matching.py:128-134)
+    Tracker(double max_dist, double max_iou, int max_age, int n_init, int budget, int metric = METRIC_COSINE)
+        : max_dist(max_dist), max_iou(max_iou), max_age(max_age), n_init(n_init), budget(budget > 0 ? budget : 32), unbounded(budget <= 0),
+          metric(metric) {
+        if (metric != METRIC_COSINE && metric != METRIC_EUCLIDEAN) fail("Invalid metric; must be either 'euclidean' or 'cosine'");
         YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         grow(256);
         YDS_HIP(hipHostMalloc((void **)&ibuf_host, IBUF_INTS * sizeof(int), hipHostMallocMapped));
@@ -455,6 +501,27 @@ public:
         mean = std::move(m); cov = std::move(c); gallery = std::move(g);
         for (int s = cap - 1; s >= capacity; --s) free_slots.push_back(s);
         capacity = cap;
+    }
+    // nn_budget=None: double the per-track row capacity, keeping every slot's rows
+    void grow_budget() {
+        const int nb = budget * 2;
+        DevBuf<float> g((size_t)capacity * nb * EMB);
+        YDS_HIP(hipMemcpy2DAsync(g.p, (size_t)nb * EMB * 4, gallery.p, (size_t)budget * EMB * 4, (size_t)budget * EMB * 4, capacity,
+                                 hipMemcpyDeviceToDevice, stream));
+        YDS_HIP(hipStreamSynchronize(stream));
+        gallery = std::move(g);
+        budget = nb;
+    }
+    // ring position for the next feature of a track (tracker.py:165-176 + nn_matching.py:152-155: last `budget` rows)
+    int next_row(Track &t) {
+        if (unbounded) {
+            if (t.n_feat == budget) grow_budget();
+            return t.n_feat++;
+        }
+        const int pos = t.head;
+        t.head = (t.head + 1) % budget;
+        t.n_feat = std::min(t.n_feat + 1, budget);
+        return pos;
     }
 
     // uploads an int vector into a scratch region and returns the device pointer
@@ -499,19 +566,29 @@ public:
     }
 
     int step(const float *tlwh_host, const float *feats, bool feats_on_device, const float *payload, int D, int32_t *out6, int cap) override {
+        return step_sel(tlwh_host, feats, feats_on_device, nullptr, payload, D, out6, cap);
+    }
+    // feat_rows (optional): detection d uses row feat_rows[d] of `feats` (tracker-side NMS keeps a subset in pick order)
+    int step_sel(const float *tlwh_host, const float *feats, bool feats_on_device, const int *feat_rows, const float *payload, int D,
+                 int32_t *out6, int cap) {
         ibuf_used = 0;
         const int T = (int)tracks.size();
         tlwh_dev.ensure((size_t)std::max(D, 1) * 4);
         if (D) YDS_HIP(hipMemcpyAsync(tlwh_dev.p, tlwh_host, (size_t)D * 16, hipMemcpyHostToDevice, stream));
         const float *feats_dev = feats;
         if (!feats_on_device && D) {
-            feats_stage.ensure((size_t)D * EMB);
-            YDS_HIP(hipMemcpyAsync(feats_stage.p, feats, (size_t)D * EMB * 4, hipMemcpyHostToDevice, stream));
+            int n_rows = D;
+            if (feat_rows) for (int d = 0; d < D; ++d) n_rows = std::max(n_rows, feat_rows[d] + 1);
+            feats_stage.ensure((size_t)n_rows * EMB);
+            YDS_HIP(hipMemcpyAsync(feats_stage.p, feats, (size_t)n_rows * EMB * 4, hipMemcpyHostToDevice, stream));
             feats_dev = feats_stage.p;
         }
-        if (D) {                                              // x / ||x|| once per frame (nn_matching.py:50-52)
+        if (D) {                                              // x / ||x|| once per frame (nn_matching.py:50-52); euclidean: as is
             feats_n.ensure((size_t)D * EMB);
-            hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, stream, feats_dev, (const int *)nullptr, feats_n.p, D);
+            const int *rows_dev = nullptr;
+            if (feat_rows) { std::vector<int> r(feat_rows, feat_rows + D); rows_dev = up(r); }
+            hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, stream, feats_dev, rows_dev, feats_n.p, D,
+                               metric == METRIC_COSINE ? 1 : 0);
         }
         // ---- Tracker.predict (tracker.py:95-113)
         if (T) {
@@ -535,7 +612,7 @@ public:
             for (int r = 0; r < Tc; ++r) { slots[r] = tracks[confirmed[r]].slot; rows[r] = tracks[confirmed[r]].n_feat; }
             cost_dev.ensure((size_t)Tc * D);
             hipLaunchKernelGGL(appearance_cost_kernel, dim3(Tc, (D + 15) / 16), dim3(256), 0, stream, gallery.p, up(slots), up(rows), budget,
-                               feats_n.p, D, mean.p, cov.p, tlwh_dev.p, (float)max_dist, (float)(max_dist + 1e-5), 1, cost_dev.p);
+                               feats_n.p, D, mean.p, cov.p, tlwh_dev.p, (float)max_dist, (float)(max_dist + 1e-5), 1, metric == METRIC_EUCLIDEAN ? 1 : 0, cost_dev.p);
             Assignment a;
             solve(cost_dev.p, Tc, D, a);
             bookkeeping(a, D, (float)max_dist, confirmed, all_dets, matches, um_t_a, um_d);
@@ -570,9 +647,7 @@ public:
             std::vector<int> slots(M), dets(M), pos(M);
             for (int k = 0; k < M; ++k) {
                 Track &t = tracks[matches[k].first];
-                slots[k] = t.slot; dets[k] = matches[k].second; pos[k] = t.head;
-                t.head = (t.head + 1) % budget;
-                t.n_feat = std::min(t.n_feat + 1, budget);
+                slots[k] = t.slot; dets[k] = matches[k].second; pos[k] = next_row(t);
                 t.hits++; t.tsu = 0;
                 if (t.state == TENTATIVE && t.hits >= n_init) t.state = CONFIRMED;
                 t.payload = payload[matches[k].second];
@@ -631,6 +706,8 @@ public:
 
     double max_dist, max_iou;       // python floats in the reference; fp32 roundings are taken where torch/numpy take them
     int max_age, n_init, budget;
+    bool unbounded = false;
+    int metric = METRIC_COSINE;
     int capacity = 0, next_id = 1;
     std::vector<Track> tracks;
     std::vector<int> free_slots;
@@ -666,6 +743,25 @@ yds_trk *yds_tracker_create(double max_dist, double max_iou_distance, int max_ag
     YDS_API_BEGIN
     return new yds_trk{new yds::Tracker(max_dist, max_iou_distance, max_age, n_init, nn_budget)};
     YDS_API_END_PTR
+}
+yds_trk *yds_tracker_create_ex(double max_dist, double max_iou_distance, int max_age, int n_init, int nn_budget, int metric) {
+    YDS_API_BEGIN
+    return new yds_trk{new yds::Tracker(max_dist, max_iou_distance, max_age, n_init, nn_budget, metric)};
+    YDS_API_END_PTR
+}
+int yds_tracker_step_sel(yds_trk *t, const float *tlwh, const float *feats, int feats_on_device, const int32_t *feat_rows, const float *payload,
+                         int D, int32_t *out6, int cap, int *m_out, int32_t *dbg_matches, int dbg_cap, int *n_matches) {
+    YDS_API_BEGIN
+    *m_out = impl(t)->step_sel(tlwh, feats, feats_on_device != 0, feat_rows, payload, D, out6, cap);
+    if (n_matches) {
+        const auto &lm = impl(t)->last_matches;
+        *n_matches = (int)lm.size();
+        if (dbg_matches) {
+            if ((int)lm.size() > dbg_cap) yds::fail("tracker: %zu matches exceed dbg_cap %d", lm.size(), dbg_cap);
+            for (size_t k = 0; k < lm.size(); ++k) { dbg_matches[2 * k] = lm[k].first; dbg_matches[2 * k + 1] = lm[k].second; }
+        }
+    }
+    YDS_API_END
 }
 void yds_tracker_destroy(yds_trk *t) {
     if (t) { delete t->t; delete t; }
@@ -795,7 +891,8 @@ int yds_iou_cost(const float *track_tlwh_host, int T, const float *det_tlwh_host
     YDS_HIP(hipStreamSynchronize(s));
     YDS_API_END
 }
-int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T, const float *feats_host, int D, int dim, float *out) {
+static int nn_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T, const float *feats_host, int D, int dim, float *out,
+                       int euclid) {
     YDS_API_BEGIN
     using namespace yds;
     if (dim != EMB) fail("cosine: feature dimension must be %d", EMB);
@@ -813,11 +910,33 @@ int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_ho
     gd.upload(g.data(), g.size(), s); fd.upload(feats_host, (size_t)D * EMB, s);
     auto v = iota(T); sl.upload(v.data(), T, s); nr.upload(rows.data(), T, s);
     const int G = T * budget;
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((G + 3) / 4), dim3(256), 0, s, gd.p, (const int *)nullptr, gn.p, G);
-    hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, s, fd.p, (const int *)nullptr, fn.p, D);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((G + 3) / 4), dim3(256), 0, s, gd.p, (const int *)nullptr, gn.p, G, euclid ? 0 : 1);
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, s, fd.p, (const int *)nullptr, fn.p, D, euclid ? 0 : 1);
     hipLaunchKernelGGL(appearance_cost_kernel, dim3(T, (D + 15) / 16), dim3(256), 0, s, gn.p, sl.p, nr.p, budget, fn.p, D,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, 0.f, 0, o.p);
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, 0.f, 0, euclid, o.p);
     YDS_HIP(hipMemcpyAsync(out, o.p, (size_t)T * D * 4, hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipStreamSynchronize(s));
+    YDS_API_END
+}
+int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T, const float *feats_host, int D, int dim, float *out) {
+    return nn_min_cost(gallery_host, seg_offsets_host, T, feats_host, D, dim, out, 0);
+}
+int yds_euclidean_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T, const float *feats_host, int D, int dim, float *out) {
+    return nn_min_cost(gallery_host, seg_offsets_host, T, feats_host, D, dim, out, 1);
+}
+int yds_tracker_nms(const float *tlwh_host, const int32_t *order_host, int D, double max_overlap, int32_t *pick_host, int *n_pick) {
+    YDS_API_BEGIN
+    using namespace yds;
+    *n_pick = 0;
+    if (D == 0) return 0;
+    for (int k = 0; k < D; ++k) if (order_host[k] < 0 || order_host[k] >= D) fail("tracker_nms: order[%d] = %d outside [0,%d)", k, order_host[k], D);
+    hipStream_t s = g_scratch.stream();
+    DevBuf<float> b; DevBuf<int> ord, pick(D), cnt(1);
+    b.upload(tlwh_host, (size_t)D * 4, s); ord.upload(order_host, D, s);
+    hipLaunchKernelGGL(tracker_nms_kernel, dim3(1), dim3(256), (size_t)D * sizeof(int), s, b.p, ord.p, D, max_overlap, pick.p, cnt.p);
+    YDS_HIP(hipGetLastError());
+    YDS_HIP(hipMemcpyAsync(n_pick, cnt.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipMemcpyAsync(pick_host, pick.p, (size_t)D * sizeof(int), hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
     YDS_API_END
 }

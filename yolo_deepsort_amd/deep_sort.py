@@ -121,11 +121,14 @@ class _TrackView:
 class _TrackerHandle:
     """Owns the C tracker; ``.tracks`` mirrors ``Tracker.tracks`` of the reference as snapshots."""
 
-    def __init__(self, max_dist, max_iou_distance, max_age, n_init, nn_budget):
-        if nn_budget is None:
-            raise ValueError("nn_budget=None (unbounded gallery) is not supported by the HIP tracker")
-        self._h = _lib.check_ptr(_lib.load().yds_tracker_create(float(max_dist), float(max_iou_distance), int(max_age),
-                                                                int(n_init), int(nn_budget)))
+    def __init__(self, max_dist, max_iou_distance, max_age, n_init, nn_budget, metric="cosine"):
+        if metric not in ("cosine", "euclidean"):
+            raise ValueError("Invalid metric; must be either 'euclidean' or 'cosine'")          # nn_matching.py:132-134
+        if nn_budget is not None and int(nn_budget) < 1:
+            raise ValueError("nn_budget must be a positive integer or None")
+        self._h = _lib.check_ptr(_lib.load().yds_tracker_create_ex(
+            float(max_dist), float(max_iou_distance), int(max_age), int(n_init), 0 if nn_budget is None else int(nn_budget),
+            1 if metric == "euclidean" else 0))
         self.device = "cuda"
 
     @property
@@ -146,7 +149,8 @@ class _TrackerHandle:
         n = t.value
         return dict(ids=ids[:n], state=state[:n], tsu=tsu[:n], hits=hits[:n], mean=mean[:n], cov=cov[:n])
 
-    def step(self, tlwh, feats, payload, feats_dev=None, want_debug=False):
+    def step(self, tlwh, feats, payload, feats_dev=None, want_debug=False, feat_rows=None):
+        """feat_rows: detection d uses row feat_rows[d] of the feature matrix (survivors of the tracker-side NMS)."""
         lib = _lib.load()
         tlwh = _np(tlwh).reshape(-1, 4)
         payload = _np(payload).reshape(-1)
@@ -154,17 +158,19 @@ class _TrackerHandle:
         cap = lib.yds_tracker_num_tracks(self._h) + d + 1
         out = np.zeros((cap, 6), np.int32)
         m = C.c_int(0)
+        rows_sel = None if feat_rows is None else np.ascontiguousarray(feat_rows, dtype=np.int32)
+        dm = np.zeros((cap, 2), np.int32)
+        nm = C.c_int(0)
         if feats_dev is not None:
-            _lib.check(lib.yds_tracker_step_dev(self._h, _lib.ptr(tlwh), feats_dev, _lib.ptr(payload), d,
-                                                _lib.ptr(out), cap, C.byref(m)))
-            dbg = None
+            src, on_dev = feats_dev, 1
         else:
-            feats = _np(feats).reshape(d, -1) if d else np.zeros((0, 512), np.float32)
-            dm = np.zeros((cap, 2), np.int32)
-            nm = C.c_int(0)
-            _lib.check(lib.yds_tracker_step(self._h, _lib.ptr(tlwh), _lib.ptr(feats), _lib.ptr(payload), d,
+            n_rows = d if rows_sel is None else (int(rows_sel.max()) + 1 if d else 0)
+            feats = _np(feats).reshape(-1, 512) if d else np.zeros((0, 512), np.float32)
+            assert feats.shape[0] >= n_rows
+            src, on_dev = _lib.ptr(feats), 0
+        _lib.check(lib.yds_tracker_step_sel(self._h, _lib.ptr(tlwh), src, on_dev, _lib.ptr(rows_sel), _lib.ptr(payload), d,
                                             _lib.ptr(out), cap, C.byref(m), _lib.ptr(dm), cap, C.byref(nm)))
-            dbg = dm[:nm.value].copy()
+        dbg = dm[:nm.value].copy()
         rows = out[:m.value].copy()
         return (rows, dbg) if want_debug else rows
 
@@ -187,7 +193,7 @@ class _TrackerHandle:
 
 class DeepSort(object):
     def __init__(self, model_path, max_dist=0.2, min_confidence=0.3, nms_max_overlap=1.0, max_iou_distance=0.7,
-                 max_age=70, n_init=3, nn_budget=100, use_cuda=False):
+                 max_age=70, n_init=3, nn_budget=100, use_cuda=False, metric="cosine"):
         self.max_dist = max_dist
         self.min_confidence = min_confidence          # unused by the reference as well (deep_sort.py:51)
         self.nms_max_overlap = nms_max_overlap
@@ -196,28 +202,46 @@ class DeepSort(object):
         self.n_init = n_init
         self.nn_budget = nn_budget
         self.use_cuda = use_cuda
-        if nms_max_overlap != 1:
-            raise NotImplementedError("tracker-side NMS (nms_max_overlap != 1) is out of scope (SURVEY 2 #9)")
         _lib.init()
         if isinstance(model_path, (str, dict)):
             self.extractor = Extractor(model_path, use_cuda=use_cuda)
         else:
             self.extractor = model_path
-        self.tracker = _TrackerHandle(max_dist, max_iou_distance, max_age, n_init, nn_budget)
+        # the reference hard-wires "cosine" (deep_sort.py:34); `metric` is this build's way to reach the other
+        # NearestNeighborDistanceMetric option (nn_matching.py:128-131)
+        self.metric = metric
+        self.tracker = _TrackerHandle(max_dist, max_iou_distance, max_age, n_init, nn_budget, metric)
 
     def clone(self):
         return DeepSort(self.extractor, self.max_dist, self.min_confidence, self.nms_max_overlap, self.max_iou_distance,
-                        self.max_age, self.n_init, self.nn_budget, self.use_cuda)
+                        self.max_age, self.n_init, self.nn_budget, self.use_cuda, self.metric)
+
+    def _nms_keep(self, tlwh):
+        """deep_sort.py:52-57 + sort/preprocessing.py:6-73: every Detection carries confidence 1 (deep_sort.py:51), so
+        ``np.argsort(scores)`` sorts a constant vector - numpy decides the order, as it does in the reference."""
+        d = tlwh.shape[0]
+        if d == 0:
+            return np.zeros(0, np.int32)
+        order = np.ascontiguousarray(np.argsort(np.ones(d, dtype=np.float64)), dtype=np.int32)
+        pick = np.zeros(d, np.int32)
+        n = C.c_int(0)
+        _lib.check(_lib.load().yds_tracker_nms(_lib.ptr(tlwh), _lib.ptr(order), d, float(self.nms_max_overlap), _lib.ptr(pick), C.byref(n)))
+        return pick[:n.value].copy()
 
     def update(self, bbox_xywh, confidences, ori_img, payload):
         self.height, self.width = ori_img.shape[:2]
         tlwh = _np(bbox_xywh).reshape(-1, 4)
         d = tlwh.shape[0]
+        payload = _np(payload).reshape(-1)
+        keep = None
         if isinstance(self.extractor, Extractor):
             hint, self.frame_source = getattr(self, "frame_source", None), None
             frame_dev = hint.last_frame_dev(ori_img) if hint is not None else None      # the detector already uploaded this frame
-            self.extractor.embed(ori_img, tlwh, to_host=False, frame_dev=frame_dev)
-            rows = self.tracker.step(tlwh, None, payload, feats_dev=self.extractor.features_dev())
+            self.extractor.embed(ori_img, tlwh, to_host=False, frame_dev=frame_dev)     # features of ALL boxes, like the reference
+            if self.nms_max_overlap != 1:
+                keep = self._nms_keep(tlwh)
+                tlwh, payload = np.ascontiguousarray(tlwh[keep]), np.ascontiguousarray(payload[keep])
+            rows = self.tracker.step(tlwh, None, payload, feats_dev=self.extractor.features_dev() if d else None, feat_rows=keep)
         else:                                          # user-supplied extractor callable (reference allows it)
             crops = []
             for x, y, w, h in tlwh:
@@ -226,7 +250,10 @@ class DeepSort(object):
                 y2 = min(int(np.float32(y + h)), self.height - 1)
                 crops.append(ori_img[y1:y2, x1:x2])
             feats = _np(self.extractor(crops)) if crops else np.zeros((0, 512), np.float32)
-            rows = self.tracker.step(tlwh, feats, payload)
+            if self.nms_max_overlap != 1:
+                keep = self._nms_keep(tlwh)
+                tlwh, payload = np.ascontiguousarray(tlwh[keep]), np.ascontiguousarray(payload[keep])
+            rows = self.tracker.step(tlwh, feats, payload, feat_rows=keep)
         return rows if len(rows) else []
 
 

@@ -191,7 +191,9 @@ class VideoDetector:
             cur, cur_dev = nxt, nxt_dev
 
     def detect(self, video_path, output_path=None, skip_secs=0, real_show=False, show_fps=True):
-        if self.batch_frames > 1 and self.tracker is not None and self.image_detector.win_size is None:
+        # (the tracker-side NMS option reorders detections on the host, so it keeps the frame-by-frame path)
+        if (self.batch_frames > 1 and self.tracker is not None and self.image_detector.win_size is None
+                and getattr(self.tracker, "nms_max_overlap", 1) == 1):
             yield from self._detect_batched(video_path)
             return
         hold_detections, actions, frames = None, [], 0
