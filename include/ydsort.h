@@ -43,6 +43,8 @@ int yds_device_pci_bus_id(char *buf, int len); /* "0000:xx:00.0" of the bound de
 const char *yds_last_error(void);            /* thread-local message of the last failing call   */
 int yds_device_count(void);
 const char *yds_build_info(void);            /* "libydsort <ver> gfx950 ..."                    */
+void *yds_host_alloc(size_t nbytes);         /* pinned host memory: uploads from it are asynchronous and full speed */
+int yds_host_free(void *host);
 void *yds_dev_alloc(size_t nbytes);
 int yds_dev_free(void *dev);
 int yds_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes);
@@ -203,6 +205,13 @@ yds_pipe *yds_pipeline_create(yds_net *, yds_reid *, yds_trk *, float conf_thres
 void yds_pipeline_destroy(yds_pipe *);
 int yds_pipeline_step(yds_pipe *, const uint8_t *frames_dev, const uint8_t *next_frames_dev, int h, int w,
                       int batch, int32_t *out6_host, int cap, int32_t *counts_host);
+/* Same with the frames in HOST memory, which is where the reference's loop starts (img_detect.py:70-71 takes a decoded
+ * frame): the upload of `next_frames_host` runs on a copy stream into the other of two device staging buffers and overlaps
+ * this call's detector / ReID / association; `frames_host` is uploaded first unless it is the pointer the previous call
+ * passed as `next_frames_host`.  Both host buffers may be reused when the call returns.  Pinned memory (yds_host_alloc)
+ * gives asynchronous full-rate copies; pageable memory works, slower. */
+int yds_pipeline_step_host(yds_pipe *, const uint8_t *frames_host, const uint8_t *next_frames_host, int h, int w,
+                           int batch, int32_t *out6_host, int cap, int32_t *counts_host);
 /* bench-only: injection set (yds_darknet_load_injection_sets) to select before the prefetched detector pass */
 int yds_pipeline_set_next_injection(yds_pipe *, int set);
 /* last step, microseconds: resize (device), detector (device), host wall until NMS results, ReID, association */

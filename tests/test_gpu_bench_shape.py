@@ -1,0 +1,70 @@
+"""Parity AT the benchmarked shape: the workloads bench.py measures - batch 16, 1920x1080 frames,
+608x608 yolov3 / yolov4 + DeepSORT, prefetch on, the crowd schedule for cfg5 - are run through yds_pipeline_step exactly
+as bench.py runs them (same Workload class) for 2 steps and compared with fixtures the REFERENCE produced on the same
+frames (oracle/gen_golden.py run_reference_stream: ImageDetector.detect -> class mask -> DeepSort.update with the real
+Extractor).  Track ids / classes / None-ness bit exact; detection and prediction floats within 1e-3."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _rows_equal(got, ref, stats):
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, 4:], ref[:, 4:])
+    bad = got[:, :4] != ref[:, :4]
+    assert np.abs(got[:, :4] - ref[:, :4]).max(initial=0) <= 1
+    stats[0] += int(bad.sum())
+    stats[1] += bad.size
+
+
+@pytest.mark.parametrize("config", ["cfg2", "cfg3", "cfg5"])
+def test_pipeline_at_bench_shape_vs_reference(config):
+    from yolo_deepsort_amd.workload import Workload, CONF_THRES, NMS_THRES
+    g = golden(f"bench_shape_{config}")
+    wl = Workload(config, batch=16)
+    B = 16
+    assert int(g["n_frames"]) == 2 * B and wl.order[:2 * B] == list(range(2 * B))
+    # ---- the composed pipeline, 2 steps, the second one prefetched under the first one's association
+    outs = wl.step(0, prefetch=True) + wl.step(1, prefetch=False)
+    stats = [0, 0]
+    for t, o in enumerate(outs):
+        if bool(g[f"f{t}_none"]):
+            assert o is None, t
+            continue
+        assert o is not None, t
+        _rows_equal(o, g[f"f{t}_out"], stats)
+    st = wl.ds.tracker.state()
+    assert np.array_equal(st["ids"], g[f"f{2 * B - 1}_ids"]) and np.array_equal(st["state"], g[f"f{2 * B - 1}_state"])
+    assert stats[1] > 2000 and stats[0] / stats[1] < 5e-3, stats          # int32 box columns off by one (fp32 truncation)
+    # ---- detector + NMS of one whole batch of 16 (the batch-16 tile variants), image by image against the reference
+    wl._pl.select_injection_set(wl.net, 1)
+    pred = wl.net.forward_u8(wl.ring[B:2 * B])
+    idx = g["sample_idx"]
+    for b in (0, 7, 15):
+        t = B + b
+        np.testing.assert_allclose(pred[b].reshape(-1)[idx], g[f"f{t}_pred"], rtol=1e-3, atol=1e-3)
+        det = wl.net.nms(b, CONF_THRES, NMS_THRES, frame_hw=(wl.H, wl.W))
+        ref = g[f"f{t}_det"]
+        assert det.shape == ref.shape and np.array_equal(det[:, 5], ref[:, 5]), t
+        np.testing.assert_allclose(det, ref, rtol=1e-3, atol=1e-3)
+
+
+def test_forward_f32_batch16_608_vs_oracle():
+    """Raw-tensor entry at batch 16, 608x608 (yolov3): two of the 16 images against the oracle's full tensors."""
+    from oracle.darknet import DarknetOracle
+    from yolo_deepsort_amd import cfgs, synth
+    from yolo_deepsort_amd.models import Darknet
+    cfg = cfgs.cfg_text("yolov3", 608, 608)
+    blob = synth.darknet_weights_blob(cfg, 0)
+    net = Darknet(None, img_size=(608, 608), batch_max=16, cfg_text=cfg)
+    net.load_darknet_weights(None, blob=blob)
+    x = np.random.RandomState(4).uniform(0, 1, (16, 3, 608, 608)).astype(F32)
+    out = np.asarray(net(x))
+    ref = DarknetOracle(cfg, 608, is_text=True)
+    ref.load_weights_array(np.frombuffer(blob, dtype=F32, offset=20))
+    for b in (3, 15):
+        np.testing.assert_allclose(out[b:b + 1], ref(x[b:b + 1]), rtol=1e-3, atol=1e-3)

@@ -9,9 +9,12 @@ F32 = np.float32
 DS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
 
 
-@pytest.mark.parametrize("name,size,batch,deep", [("yolov3-tiny", 416, 4, False), ("yolov4-tiny", 416, 3, False),
-                                                  ("yolov3-tiny", 416, 4, True)])
-def test_pipeline_matches_oracle_stream(name, size, batch, deep, monkeypatch):
+@pytest.mark.parametrize("name,size,batch,deep,frames_in", [("yolov3-tiny", 416, 4, False, "hbm"), ("yolov4-tiny", 416, 3, False, "hbm"),
+                                                            ("yolov3-tiny", 416, 4, True, "hbm"), ("yolov3-tiny", 416, 4, False, "pinned"),
+                                                            ("yolov3-tiny", 416, 4, True, "pageable")])
+def test_pipeline_matches_oracle_stream(name, size, batch, deep, frames_in, monkeypatch):
+    # frames_in: resident in HBM (yds_pipeline_step) or handed over as host memory and uploaded by the pipeline on its
+    # copy stream, double buffered (yds_pipeline_step_host; pinned = asynchronous copies, pageable = any numpy array)
     # deep: the crowded-scene schedule (next batch's NMS + ReID started before this batch's association) forced on
     monkeypatch.setenv("YDS_PIPE_DEEP_MIN", "0" if deep else "1000000")
     from oracle.darknet import DarknetOracle
@@ -41,15 +44,30 @@ def test_pipeline_matches_oracle_stream(name, size, batch, deep, monkeypatch):
     inj[5] = inj[5][:0]                         # a frame where the detector returns None
     pl.load_injection_sets(net, [[inj[s * batch + b] for b in range(batch)] for s in range(n // batch)])
     pipe = pl.Pipeline(net, ds, 0.5, 0.4, class_mask=[0, 2, 4])
-    dev = _lib.DeviceBuffer.from_array(frames)
     got = []
     steps = n // batch
     pl.select_injection_set(net, 0)
-    for s in range(steps):
-        # all but the last step hand the next batch over early (detector prefetch overlapping the association)
-        nxt = dev.offset((s + 1) * batch * frames[0].nbytes) if s + 1 < steps else None
-        got += pipe.step(dev.offset(s * batch * frames[0].nbytes), 480, 640, batch, nxt,
-                         select_next=(s + 1 if nxt is not None else None))
+    if frames_in == "hbm":
+        dev = _lib.DeviceBuffer.from_array(frames)
+        for s in range(steps):
+            # all but the last step hand the next batch over early (detector prefetch overlapping the association)
+            nxt = dev.offset((s + 1) * batch * frames[0].nbytes) if s + 1 < steps else None
+            got += pipe.step(dev.offset(s * batch * frames[0].nbytes), 480, 640, batch, nxt,
+                             select_next=(s + 1 if nxt is not None else None))
+    else:
+        # a decoder's two-buffer ring: the batch after next overwrites the buffer of the batch that just finished
+        if frames_in == "pinned":
+            hold = [_lib.PinnedArray((batch, 480, 640, 3)), _lib.PinnedArray((batch, 480, 640, 3))]
+            bufs = [h.array for h in hold]
+        else:
+            bufs = [np.empty((batch, 480, 640, 3), np.uint8), np.empty((batch, 480, 640, 3), np.uint8)]
+        bufs[0][:] = frames[:batch]
+        for s in range(steps):
+            nxt = None
+            if s + 1 < steps:
+                nxt = bufs[(s + 1) % 2]
+                nxt[:] = frames[(s + 1) * batch:(s + 2) * batch]
+            got += pipe.step_host(bufs[s % 2], nxt, select_next=(s + 1 if nxt is not None else None))
     ref_net = DarknetOracle(cfg, size, is_text=True)
     ref_net.load_weights_array(np.frombuffer(blob, dtype=F32, offset=20))
     want = run_stream(ref_net, sd, DS, frames, inj)
@@ -107,3 +125,44 @@ def test_video_detector_batched_lookahead_equals_frame_by_frame():
         assert np.abs(d1[:, :4] - d4[:, :4]).max(initial=0) <= 1, t
         rows += len(d1)
     assert rows > 0
+
+
+def test_frame_by_frame_device_crop_path_equals_host_feature_path():
+    """VideoDetector.process hands the detector's device copy of the frame to the extractor and the features stay in HBM
+    (yds_reid_embed_dev -> yds_tracker_step_sel); the extractor's pass must be complete before the tracker's stream reads
+    it.  Same stream through the host-feature path: identical rows, frame after frame, with person
+    textures that move so that stale features would change the costs."""
+    import os
+    import tempfile
+    from yolo_deepsort_amd import _lib
+    from yolo_deepsort_amd.deep_sort import DeepSort
+    from yolo_deepsort_amd.detect import VideoDetector, p1p2Toxywh
+    from yolo_deepsort_amd.models import Darknet
+    _lib.init(0)
+    cfg = cfgs.cfg_text("yolov3-tiny", 416, 416)
+    blob = synth.darknet_weights_blob(cfg, 0)
+    sd = synth.reid_state_dict(0)
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+    net = Darknet(None, img_size=(416, 416), cfg_text=cfg)
+    net.load_darknet_weights(None, blob=blob)
+    scene = synth.PersonScene(12, frame_hw=(480, 640), seed=8, occlude_frac=0.1)
+    vd = VideoDetector(net, f.name, thres=0.5, nms_thres=0.4, tracker=DeepSort(sd, use_cuda=True, **DS), class_mask=[0])
+    os.unlink(f.name)
+    ds2 = DeepSort(vd.tracker.extractor, use_cuda=True, **DS)            # shares the extractor, own tracker (clone semantics)
+    heads = net.yolo_heads()
+    rows_seen = 0
+    for t in range(12):
+        frame = scene.frame(t)
+        net.set_injection(0, synth.head_injection(scene.boxes(t)[1], (480, 640), (416, 416), heads))
+        got = vd.process(frame)
+        det = vd.image_detector.detect(frame)
+        det = det.numpy() if hasattr(det, "numpy") else det
+        det = det[det[:, 5] == 0]
+        tlwh = p1p2Toxywh(det[:, :4]).astype(F32)
+        feats = ds2.extractor.embed(frame, tlwh, to_host=True)
+        want = ds2.tracker.step(tlwh, feats, det[:, 5])
+        got = np.array(got, np.int32).reshape(-1, 6)
+        assert np.array_equal(got, want), t
+        rows_seen += len(want)
+    assert rows_seen > 50

@@ -34,6 +34,8 @@ SIGNATURES = {
     "yds_current_device": (_I, []),
     "yds_device_pci_bus_id": (_I, [C.c_char_p, _I]),
     "yds_build_info": (C.c_char_p, []),
+    "yds_host_alloc": (_P, [_SZ]),
+    "yds_host_free": (_I, [_P]),
     "yds_dev_alloc": (_P, [_SZ]),
     "yds_dev_free": (_I, [_P]),
     "yds_memcpy_h2d": (_I, [_P, _P, _SZ]),
@@ -99,6 +101,7 @@ SIGNATURES = {
     "yds_pipeline_create": (_P, [_P, _P, _P, _F, _F, _P, _I]),
     "yds_pipeline_destroy": (None, [_P]),
     "yds_pipeline_step": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "yds_pipeline_step_host": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "yds_pipeline_set_next_injection": (_I, [_P, _I]),
     "yds_pipeline_stage_us": (_I, [_P, _P]),
     "yds_conv_timing": (_I, [_P, _I, _P, _P, _P]),
@@ -192,6 +195,36 @@ def ptr(a):
 
 def as_f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class PinnedArray:
+    """numpy view of pinned host memory (yds_host_alloc): uploads from it are asynchronous (decoders write frames here)."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self.shape, self.dtype = tuple(int(v) for v in shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = check_ptr(load().yds_host_alloc(self.nbytes))
+        buf = (C.c_uint8 * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    @classmethod
+    def from_array(cls, a):
+        a = np.asarray(a)
+        p = cls(a.shape, a.dtype)
+        np.copyto(p.array, a)
+        return p
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            load().yds_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

@@ -27,12 +27,45 @@ public:
         : net(net), reid(reid), trk(trk), conf(conf), nms_thres(nms_iou), class_mask(mask, mask + n_mask) {
         for (int k = 0; k < 2; ++k) {
             for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
+            YDS_HIP(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
             nms[k].reset(new NmsWorkspace(4096, net->batch_max));
         }
+        YDS_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     }
     ~Pipeline() {
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k) {
             for (hipEvent_t e : {e0[k], e1[k], e2[k], e_nms[k]}) (void)hipEventDestroy(e);
+            (void)hipEventDestroy(up_done[k]);
+        }
+        (void)hipStreamDestroy(copy_stream);
+    }
+
+    // ---- frames handed over as HOST memory (img_detect.py:70-71 starts from a host frame) ------------------------------
+    // Two device staging buffers alternate; the copy runs on its own stream (SDMA engine), so the upload of batch i+1
+    // overlaps the detector / ReID / association of batch i.  The detector stream waits for the upload event of the
+    // buffer it is about to read.  Pinned source memory (yds_host_alloc) makes the copy asynchronous and full speed.
+    const uint8_t *upload(const uint8_t *host, size_t bytes) {
+        const int k = (stage_turn ^= 1);
+        stage[k].ensure(bytes);
+        YDS_HIP(hipMemcpyAsync(stage[k].p, host, bytes, hipMemcpyHostToDevice, copy_stream));
+        YDS_HIP(hipEventRecord(up_done[k], copy_stream));
+        stage_host[k] = host;
+        return stage[k].p;
+    }
+    void step_host(const uint8_t *frames_host, const uint8_t *next_host, int next_inject_set, int h, int w, int batch, int32_t *out6, int cap,
+                   int32_t *counts) {
+        const size_t bytes = (size_t)batch * h * w * 3;
+        const uint8_t *cur_dev = nullptr;
+        // the batch handed over as `next` by the previous call is already resident (or on its way)
+        if (prefetched_host && prefetched_host == frames_host && stage_host[stage_turn] == frames_host) cur_dev = stage[stage_turn].p;
+        else cur_dev = upload(frames_host, bytes);
+        const uint8_t *next_dev = nullptr;
+        int next_k = -1;
+        if (next_host) { next_dev = upload(next_host, bytes); next_k = stage_turn; }
+        prefetched_host = next_host;
+        step(cur_dev, next_dev, next_inject_set, h, w, batch, out6, cap, counts);
+        // both host buffers may be reused by the caller when this returns
+        if (next_k >= 0) YDS_HIP(hipEventSynchronize(up_done[next_k]));
     }
 
     // One detector pass over a batch AND its NMS, all asynchronous on the detector stream.  Two NMS workspaces (and
@@ -40,6 +73,8 @@ public:
     // for and read the results of batch i: the detector stream never drains between passes.
     void launch_detector(const uint8_t *frames_dev, int h, int w, int batch, int slot = -1) {
         const int k = slot >= 0 ? slot : (in_flight_slot ^= 1);
+        for (int b = 0; b < 2; ++b)                                 // frames uploaded by step_host: wait for the copy engine
+            if (stage[b].p && frames_dev == stage[b].p) YDS_HIP(hipStreamWaitEvent(net->stream, up_done[b], 0));
         YDS_HIP(hipEventRecord(e0[k], net->stream));
         launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream);
         YDS_HIP(hipEventRecord(e1[k], net->stream));
@@ -171,6 +206,12 @@ public:
     std::unique_ptr<NmsWorkspace> nms[2];
     int in_flight_slot = 0;
     int last_h = 0, last_w = 0;
+    DevBuf<uint8_t> stage[2];                 // device copies of host frames (step_host)
+    const uint8_t *stage_host[2] = {nullptr, nullptr};
+    const uint8_t *prefetched_host = nullptr;
+    hipEvent_t up_done[2] = {};
+    hipStream_t copy_stream = nullptr;
+    int stage_turn = 0;
     Dets cur, ahead;                // this batch; the next batch when its ReID pass was started early
     DevBuf<float> feat_cur;
     int next_inject_set = -1;      // bench-only: injection set of the prefetched detector pass
@@ -199,6 +240,13 @@ int yds_pipeline_step(yds_pipe *p, const uint8_t *frames_dev, const uint8_t *nex
                       int cap, int32_t *counts_host) {
     YDS_API_BEGIN
     p->p->step(frames_dev, next_frames_dev, p->p->next_inject_set, h, w, batch, out6_host, cap, counts_host);
+    p->p->next_inject_set = -1;
+    YDS_API_END
+}
+int yds_pipeline_step_host(yds_pipe *p, const uint8_t *frames_host, const uint8_t *next_frames_host, int h, int w, int batch,
+                           int32_t *out6_host, int cap, int32_t *counts_host) {
+    YDS_API_BEGIN
+    p->p->step_host(frames_host, next_frames_host, p->p->next_inject_set, h, w, batch, out6_host, cap, counts_host);
     p->p->next_inject_set = -1;
     YDS_API_END
 }

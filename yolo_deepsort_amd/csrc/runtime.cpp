@@ -88,6 +88,20 @@ void *yds_dev_alloc(size_t nbytes) {
     YDS_API_END_PTR
 }
 
+void *yds_host_alloc(size_t nbytes) {
+    YDS_API_BEGIN
+    void *p = nullptr;
+    YDS_HIP(hipHostMalloc(&p, nbytes ? nbytes : 1, hipHostMallocDefault));
+    return p;
+    YDS_API_END_PTR
+}
+
+int yds_host_free(void *host) {
+    YDS_API_BEGIN
+    if (host) YDS_HIP(hipHostFree(host));
+    YDS_API_END
+}
+
 int yds_dev_free(void *dev) {
     YDS_API_BEGIN
     if (dev) YDS_HIP(hipFree(dev));

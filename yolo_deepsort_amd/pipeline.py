@@ -30,6 +30,22 @@ class Pipeline:
                                                  _lib.ptr(counts)))
         return [None if counts[b] < 0 else out[b, :counts[b]].copy() for b in range(batch)]
 
+    def step_host(self, frames, next_frames=None, select_next=None):
+        """frames / next_frames: uint8 [batch,h,w,3] HOST arrays (C-contiguous; views of a _lib.PinnedArray upload
+        asynchronously).  The upload of next_frames overlaps this call's work; the next call must pass the same array
+        object's memory as `frames`."""
+        assert frames.dtype == np.uint8 and frames.ndim == 4 and frames.flags["C_CONTIGUOUS"]
+        batch, h, w, _ = frames.shape
+        if next_frames is not None:
+            assert next_frames.shape == frames.shape and next_frames.dtype == np.uint8 and next_frames.flags["C_CONTIGUOUS"]
+        out = np.zeros((batch, self.cap, 6), np.int32)
+        counts = np.zeros(batch, np.int32)
+        if select_next is not None:
+            _lib.check(_lib.load().yds_pipeline_set_next_injection(self._h, int(select_next)))
+        _lib.check(_lib.load().yds_pipeline_step_host(self._h, _lib.ptr(frames), _lib.ptr(next_frames), h, w, batch, _lib.ptr(out),
+                                                      self.cap, _lib.ptr(counts)))
+        return [None if counts[b] < 0 else out[b, :counts[b]].copy() for b in range(batch)]
+
     def stage_us(self):
         us = np.zeros(5, np.float32)
         _lib.check(_lib.load().yds_pipeline_stage_us(self._h, _lib.ptr(us)))
