@@ -217,6 +217,30 @@ class DarknetOracle:
     __call__ = forward
 
 
+def yolo_heads(oracle, H, W):
+    """[(h, w, [(aw, ah) ...])] per yolo layer in network order (what the product's Darknet.yolo_heads() reports)."""
+    sizes, heads = [], []
+    h, w = H, W
+    for d, p in zip(oracle.module_defs, oracle.params):
+        t = d["type"]
+        if t == "convolutional":
+            h = (h + 2 * p["pad"] - p["k"]) // p["stride"] + 1
+            w = (w + 2 * p["pad"] - p["k"]) // p["stride"] + 1
+        elif t == "maxpool":
+            k, s = int(d["size"]), int(d["stride"])
+            if not (k == 2 and s == 1):
+                pad = (k - 1) // 2
+                h, w = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+        elif t == "upsample":
+            h, w = h * int(d["stride"]), w * int(d["stride"])
+        elif t == "route":
+            h, w = sizes[int(d["layers"].split(",")[0])]
+        elif t == "yolo":
+            heads.append((h, w, list(p["anchors"])))
+        sizes.append((h, w))
+    return heads
+
+
 def conv_flops(oracle, H, W):
     """2*MAC over conv layers for an HxW input (SURVEY 8d algorithmic FLOPs)."""
     shapes = []

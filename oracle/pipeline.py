@@ -30,10 +30,14 @@ def make_injector(net, rows, logit=6.0):
     return inject
 
 
-def run_stream(net, reid_sd, ds_params, frames, inj_rows=None, conf=0.5, nms_thres=0.4, class_mask=(0, 2, 4)):
-    """Returns one entry per frame: int32 [m,6] rows, [] (tracker found nothing) or None (detector None)."""
+def run_stream(net, reid_sd, ds_params, frames, inj_rows=None, conf=0.5, nms_thres=0.4, class_mask=(0, 2, 4), reid_fn=None):
+    """Returns one entry per frame: int32 [m,6] rows, [] (tracker found nothing) or None (detector None).
+    net: DarknetOracle or fast.DarknetFast; reid_fn (optional): callable crops -> features (fast.ReidFast)."""
     S = net.img_size
     trk = otrk.TrackerOracle(**ds_params)
+    if reid_fn is None:
+        def reid_fn(crops):
+            return oreid.reid_forward(crops, reid_sd)
     outs = []
     for t, frame in enumerate(frames):
         x = resize_bilinear_u8(frame, (S[1], S[0])).astype(F32).transpose(2, 0, 1)[None] / F32(255.)
@@ -50,6 +54,6 @@ def run_stream(net, reid_sd, ds_params, frames, inj_rows=None, conf=0.5, nms_thr
         if class_mask is None or len(class_mask) == 0:
             keep[:] = True
         tlwh = onms.p1p2_to_xywh(det[keep, :4])
-        feats = oreid.reid_forward(oreid.preprocess_crops(frame, tlwh), reid_sd) if len(tlwh) else np.zeros((0, 512), F32)
+        feats = reid_fn(oreid.preprocess_crops(frame, tlwh)) if len(tlwh) else np.zeros((0, 512), F32)
         outs.append(trk.update(tlwh, feats, det[keep, 5]))
     return outs

@@ -249,12 +249,24 @@ __global__ void inject_clear_kernel(float *head, int image, int H, int W, int ld
         head[((size_t)image * H * W + cell) * ld + a * attrs + 4] = -logit;
     }
 }
+// Two scripted boxes can land on the same (head, anchor, cell).  The rows are applied "in order, the last one wins" (what a
+// sequential loop does, oracle/pipeline.py make_injector): a row is skipped when a later row of the table targets its cell,
+// so that the parallel writes never race.
+__device__ __forceinline__ bool inject_row_superseded(const float *rows, int r, int n) {
+    const float *row = rows + (size_t)r * 9;
+    for (int j = r + 1; j < n; ++j) {
+        const float *o = rows + (size_t)j * 9;
+        if (o[0] == row[0] && o[1] == row[1] && o[2] == row[2] && o[3] == row[3]) return true;
+    }
+    return false;
+}
 __global__ void inject_rows_kernel(float *head, int image, int H, int W, int ld, int attrs, const float *rows, int n, int head_index,
                                    float logit) {
     int r = blockIdx.x;
     if (r >= n) return;
     const float *row = rows + r * 9;
     if ((int)row[0] != head_index) return;
+    if (inject_row_superseded(rows, r, n)) return;
     int a = (int)row[1], gy = (int)row[2], gx = (int)row[3], cls = (int)row[8];
     float *cell = head + ((size_t)(image * H + gy) * W + gx) * ld + a * attrs;
     for (int t = threadIdx.x; t < attrs; t += blockDim.x) {
@@ -290,6 +302,7 @@ __global__ void inject_rows_batch_kernel(float *head, int H, int W, int ld, int 
     if (r >= n) return;
     const float *row = table + (size_t)(o0 + r) * 9;
     if ((int)row[0] != head_index) return;
+    if (inject_row_superseded(table + (size_t)o0 * 9, r, n)) return;
     int a = (int)row[1], gy = (int)row[2], gx = (int)row[3], cls = (int)row[8];
     float *cell = head + ((size_t)(image * H + gy) * W + gx) * ld + a * attrs;
     for (int t = threadIdx.x; t < attrs; t += blockDim.x) {
