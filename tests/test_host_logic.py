@@ -235,3 +235,47 @@ def test_resize_restatement_geometry_vs_torch_interpolate():
         assert np.abs(diff).mean() < 0.3
         assert 0.05 < (got != np.rint(ref)).mean() < 0.2          # the fp32-lerp + rint definition of round 1 was NOT cv2's
         assert got.shape == (dh, dw, 3)
+
+
+def test_label_drawer_and_file_video_stream():
+    """SURVEY 8f row 4 host stages: LabelDrawer (label_draw.py:118-191) and the FileVideoStream reader role."""
+    from yolo_deepsort_amd.detect import FileVideoStream, _transform
+    from yolo_deepsort_amd.label_draw import LabelDrawer
+    names = ["person", "bicycle", "car"]
+    d = LabelDrawer(names, None, 10, 2, (608, 608))
+    state = np.random.get_state()[1][:4].copy()
+    np.random.seed(1)                                         # the reference's colour table (label_draw.py:140-146)
+    ref_colors = [tuple(int(v) for v in c) for c in (np.random.rand(3, 3) * 255).astype(int)]
+    np.random.seed(None)
+    assert d.colors == ref_colors
+    img = np.zeros((240, 320, 3), np.uint8)
+    rows = np.array([[20, 60, 120, 200, 7, 0], [150, 30, 300, 110, 12, 2]], np.int32)
+    out, _, _ = d.draw_labels_by_trackers(img, rows, only_rect=False)
+    assert out is img
+    assert tuple(img[60, 70]) == d.colors[0] and tuple(img[200, 70]) == d.colors[0]          # top / bottom edge of box 0
+    assert tuple(img[70, 150]) == d.colors[2] and tuple(img[130, 70]) == (0, 0, 0)           # left edge of box 1 / interior untouched
+    assert (img[40:58, 20:60] == 0).all(axis=-1).any() and (img[40:58, 20:60] == d.colors[0]).all(axis=-1).any()   # plate with black text
+    img2 = np.zeros((240, 320, 3), np.uint8)
+    d.draw_labels_by_trackers(img2, rows, only_rect=True)
+    assert (img2[40:58, 20:60] == 0).all()                                                    # no plate
+    det = np.array([[10, 10, 50, 80, 0.9, 0.8, 1]], np.float32)
+    d.draw_labels(np.zeros((240, 320, 3), np.uint8), det, only_rect=False)
+    assert d.draw_labels(img, None, False)[0] is img
+    # frame reader: .npy source, BGR -> RGB on the reader thread, bounded queue, end of stream
+    frames = np.random.RandomState(0).randint(0, 256, (5, 8, 6, 3)).astype(np.uint8)
+    with tempfile.NamedTemporaryFile(suffix=".npy", delete=False) as f:
+        np.save(f, frames)
+    try:
+        fvs = FileVideoStream(f.name, _transform, queue_size=2).start()
+        got = []
+        while fvs.more():
+            fr = fvs.read()
+            if fr is None:
+                break
+            got.append(fr)
+        fvs.stop()
+    finally:
+        os.unlink(f.name)
+    assert len(got) == 5 and all(np.array_equal(g, fr[:, :, ::-1]) for g, fr in zip(got, frames))
+    with pytest.raises(IOError):
+        FileVideoStream("/nonexistent/video.mp4")

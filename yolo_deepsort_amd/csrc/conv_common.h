@@ -108,6 +108,31 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
         if (n + 1 < p.Cout) bias4.y = p.bias[n + 1];
         if (n + 2 < p.Cout) bias4.z = p.bias[n + 2];
     }
+    // The residual rows of ALL passes are fetched up front: the loads are in flight while the first wave row goes through
+    // LDS, instead of paying one exposed global-load latency per pass (each pass sits between two barriers).
+    constexpr int PER_PASS = ROWS / RSTEP, NRES = RES != RES_NONE ? WM * PER_PASS : 1;
+    float4 rraw[NRES];
+    if (RES != RES_NONE) {
+#pragma unroll
+        for (int q = 0; q < NRES; ++q) {
+            const int m = rows((q / PER_PASS) * ROWS + rr + (q % PER_PASS) * RSTEP);
+            rraw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m >= 0 && m < p.M && n < p.Cout) {
+                const float *rp = p.res + (size_t)m * p.ldr;
+                if (p.fmt_r == FMT_H16) {                                      // H16 tensors have Cout % 32 == 0: [hi 8 B | lo 8 B]
+                    const char *g = reinterpret_cast<const char *>(rp + (n & ~31)) + (n & 31) * 2;
+                    const float2 hi = *reinterpret_cast<const float2 *>(g), lo = *reinterpret_cast<const float2 *>(g + 64);
+                    rraw[q] = make_float4(hi.x, hi.y, lo.x, lo.y);
+                } else if (n_vec) {
+                    rraw[q] = *reinterpret_cast<const float4 *>(rp + n);
+                } else {
+                    rraw[q].x = rp[n];
+                    if (n + 1 < p.Cout) rraw[q].y = rp[n + 1];
+                    if (n + 2 < p.Cout) rraw[q].z = rp[n + 2];
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int pass = 0; pass < WM; ++pass) {
         if (wm == pass) {
@@ -121,16 +146,20 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
         }
         __syncthreads();
 #pragma unroll
-        for (int r = rr; r < ROWS; r += RSTEP) {
+        for (int k2 = 0; k2 < PER_PASS; ++k2) {
+            const int r = rr + k2 * RSTEP;
             const int m = rows(pass * ROWS + r);
             const bool live = m >= 0 && m < p.M && n < p.Cout;   // no early exit: lane pairs trade halves below
             float4 v = *reinterpret_cast<const float4 *>(stage + r * LD + c4 * 4);
             float rs[4] = {0.f, 0.f, 0.f, 0.f};
             if (RES != RES_NONE && live) {
-                const float *rp = p.res + (size_t)m * p.ldr;
-                if (p.fmt_r == FMT_H16) h16_load4(rp, n, rs);                  // H16 tensors have Cout % 32 == 0
-                else if (n_vec) { float4 t = *reinterpret_cast<const float4 *>(rp + n); rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
-                else { rs[0] = rp[n]; if (n + 1 < p.Cout) rs[1] = rp[n + 1]; if (n + 2 < p.Cout) rs[2] = rp[n + 2]; }
+                const float4 t = rraw[RES != RES_NONE ? pass * PER_PASS + k2 : 0];
+                if (p.fmt_r == FMT_H16) {
+                    union { float2 f; h16x4 h; } uh, ul;
+                    uh.f = make_float2(t.x, t.y);
+                    ul.f = make_float2(t.z, t.w);
+                    h16_decode4(uh.h, ul.h, rs);
+                } else { rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
             }
             float o[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
 #pragma unroll

@@ -10,6 +10,7 @@ from functools import reduce
 
 import numpy as np
 
+from .label_draw import LabelDrawer, put_text
 from .loaders import load_classes
 
 
@@ -70,13 +71,71 @@ class ImageDetector:
         return _as_tensor(det)
 
 
-class _NullDrawer:
-    """Stand-in for LabelDrawer (host-side rendering is out of scope, SURVEY 2 #12)."""
+class FileVideoStream:
+    """Threaded frame reader with a bounded queue and a per-frame transform - the role of ``imutils.video.FileVideoStream``
+    in the reference (yolo3/detect/video_detect.py:12,86,112-126: ``FileVideoStream(path, _transform).start()``, ``more()``,
+    ``read()``).  Sources: a video file / camera index through cv2.VideoCapture when cv2 is installed, or an ``.npy`` file
+    holding uint8 [N,H,W,3] frames (what the tests and synthetic streams use).  Frames are BGR like cv2's; ``transform``
+    is applied on the reader thread (the reference passes BGR->RGB)."""
 
-    def draw_labels(self, frame, detections, only_rect=False):
-        return frame, None, None
+    def __init__(self, path, transform=None, queue_size=128):
+        import queue
+        self.transform = transform
+        self.stopped = False
+        self.Q = queue.Queue(maxsize=queue_size)
+        self._frames = None
+        self._cap = None
+        if isinstance(path, str) and path.endswith(".npy"):
+            self._frames = iter(np.load(path, mmap_mode="r"))
+        else:
+            try:
+                import cv2
+            except ImportError:
+                raise IOError("Couldn't open webcam or video")
+            self._cap = cv2.VideoCapture(path)
+            if not self._cap.isOpened():
+                raise IOError("Couldn't open webcam or video")
+        self._thread = None
 
-    draw_labels_by_trackers = draw_labels
+    def start(self):
+        import threading
+        self._thread = threading.Thread(target=self._update, daemon=True)
+        self._thread.start()
+        return self
+
+    def _next(self):
+        if self._frames is not None:
+            f = next(self._frames, None)
+            return None if f is None else np.array(f)
+        ok, f = self._cap.read()
+        return f if ok else None
+
+    def _update(self):
+        while not self.stopped:
+            frame = self._next()
+            if frame is None:
+                break
+            if self.transform is not None:
+                frame = self.transform(frame)
+            self.Q.put(frame)
+        self.stopped = True
+        self.Q.put(None)                      # end marker wakes a blocked reader
+
+    def more(self):
+        return not (self.stopped and self.Q.empty())
+
+    def read(self):
+        return self.Q.get()
+
+    def stop(self):
+        self.stopped = True
+        if self._cap is not None:
+            self._cap.release()
+
+
+def _transform(frame):
+    """video_detect.py:33-36: BGR -> RGB"""
+    return None if frame is None else np.ascontiguousarray(frame[:, :, ::-1])
 
 
 class VideoDetector:
@@ -95,7 +154,9 @@ class VideoDetector:
         self.class_mask = class_mask
         self.tracker = tracker
         self.action_id = action_id
-        self.label_drawer = _NullDrawer()
+        self._fps_prev, self._fps_acc, self._fps_cnt, self._fps_text = time.time(), 0.0, 0, "FPS: ??"
+        self.label_drawer = LabelDrawer(self.class_names, font_path=font_path, font_size=font_size, thickness=thickness,
+                                        img_size=getattr(model, "img_size", None))
         self.image_detector = ImageDetector(model, class_path, thickness=thickness, thres=thres, nms_thres=nms_thres,
                                             win_size=win_size, overlap=overlap, half=half)
 
@@ -104,18 +165,15 @@ class VideoDetector:
             for f in video_path:           # already-decoded RGB frames
                 yield f
             return
+        fvs = FileVideoStream(video_path, _transform).start()       # video_detect.py:86: decode thread + BGR -> RGB
         try:
-            import cv2
-        except ImportError:
-            raise IOError("Couldn't open webcam or video")
-        cap = cv2.VideoCapture(video_path)
-        if not cap.isOpened():
-            raise IOError("Couldn't open webcam or video")
-        while True:
-            ok, frame = cap.read()
-            if not ok:
-                return
-            yield frame[:, :, ::-1]        # BGR -> RGB like video_detect.py:33-36
+            while fvs.more():
+                frame = fvs.read()
+                if frame is None:
+                    return
+                yield frame
+        finally:
+            fvs.stop()
 
     def process(self, frame):
         """The hot glue of video_detect.py:134-157 for one frame: returns hold_detections."""
@@ -151,7 +209,29 @@ class VideoDetector:
         if group:
             yield group
 
-    def _detect_batched(self, video_path):
+    def _render(self, frame, hold_detections, show_fps):
+        """video_detect.py:161-186: overlay (on a copy: callers may hand in their own frame arrays), RGB -> BGR, FPS text."""
+        image = frame
+        if hold_detections is not None and len(hold_detections):
+            image = frame.copy()
+            if self.tracker is not None:
+                self.label_drawer.draw_labels_by_trackers(image, hold_detections, only_rect=False)
+            else:
+                self.label_drawer.draw_labels(image, hold_detections, only_rect=False)
+        result = np.ascontiguousarray(image[:, :, ::-1])           # RGB -> BGR
+        now = time.time()
+        self._fps_acc += now - self._fps_prev
+        self._fps_prev = now
+        self._fps_cnt += 1
+        if self._fps_acc > 1:
+            self._fps_acc -= 1
+            self._fps_text = "FPS: " + str(self._fps_cnt)
+            self._fps_cnt = 0
+        if show_fps:
+            put_text(result, self._fps_text, (3, 15), 2, (255, 0, 0))
+        return result
+
+    def _detect_batched(self, video_path, show_fps=True):
         """detect() through the batched pipeline: identical per-frame results, frames are read batch_frames ahead."""
         from . import _lib, pipeline as pl
         det = self.image_detector
@@ -185,7 +265,7 @@ class VideoDetector:
                     hold_detections = None if o is None else (o if len(o) else [])
                     if self.action_id is not None and hold_detections is not None:
                         actions = self.action_id.update(hold_detections)
-                yield np.ascontiguousarray(frame[:, :, ::-1]), hold_detections, actions
+                yield self._render(frame, hold_detections, show_fps), hold_detections, actions
             if cur_dev is not None:
                 cur_dev[0].free()
             cur, cur_dev = nxt, nxt_dev
@@ -194,7 +274,7 @@ class VideoDetector:
         # (the tracker-side NMS option reorders detections on the host, so it keeps the frame-by-frame path)
         if (self.batch_frames > 1 and self.tracker is not None and self.image_detector.win_size is None
                 and getattr(self.tracker, "nms_max_overlap", 1) == 1):
-            yield from self._detect_batched(video_path)
+            yield from self._detect_batched(video_path, show_fps)
             return
         hold_detections, actions, frames = None, [], 0
         for frame in self._frames(video_path):
@@ -209,13 +289,6 @@ class VideoDetector:
                 frames = 0
             else:
                 actions = []
-            if hold_detections is not None:
-                if self.tracker is not None:
-                    image, _, _ = self.label_drawer.draw_labels_by_trackers(frame, hold_detections, only_rect=False)
-                else:
-                    image, _, _ = self.label_drawer.draw_labels(frame, hold_detections, only_rect=False)
-            else:
-                image = frame
-            result = np.ascontiguousarray(image[:, :, ::-1])       # RGB -> BGR
+            result = self._render(frame, hold_detections, show_fps)
             frames += 1
             yield result, hold_detections, actions
