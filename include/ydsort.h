@@ -72,6 +72,10 @@ int yds_darknet_load_weights(yds_net *, const void *blob_host, size_t nbytes, in
  * to the handle (pipelines) stay valid.  The reference's Darknet takes any batch size (models.py:292). */
 int yds_darknet_set_batch_max(yds_net *, int batch_max);
 int yds_darknet_batch_max(const yds_net *);
+/* model.half() of ImageDetector(half=True) (yolo3/detect/img_detect.py:49-50,81-82): the detector's convolutions take
+ * single-term fp16 operands (weights and activations rounded to fp16, fp32 accumulation in the matrix cores) instead
+ * of the default split-fp16 arithmetic.  Accuracy is fp16-class, not the 1e-3 of the default mode (tests state it). */
+int yds_darknet_set_half(yds_net *, int on);
 int yds_darknet_num_boxes(const yds_net *);
 int yds_darknet_num_attrs(const yds_net *);                 /* 5 + classes                     */
 int yds_darknet_num_layers(const yds_net *);

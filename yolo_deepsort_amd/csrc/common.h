@@ -91,6 +91,7 @@ struct ConvArgs {
     View res;              // optional residual (same n,h,w,c as y)
     int ksize = 1, stride = 1, pad = 0, kpad = 0;
     int act = ACT_LINEAR, res_mode = RES_NONE;
+    int terms = 3;         // f16x3 kernels: 3 = split-fp16 (fp32-class), 1 = single-term fp16 operands ("half" mode of a detector)
 };
 // returns the tile-variant id that was launched (see conv_variant_name)
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice

@@ -228,6 +228,7 @@ ConvKernelArgs make_conv_args(const ConvArgs &a) {
     k.M = (int)a.y.pixels();
     k.act = a.act; k.res_mode = a.res.p ? a.res_mode : RES_NONE;
     k.fmt_x = a.x.fmt; k.fmt_y = a.y.fmt; k.fmt_r = a.res.p ? a.res.fmt : FMT_F32;
+    k.terms = a.terms == 1 ? 1 : 3;
     if (a.x.fmt == FMT_H16 && (a.x.c % 32 || a.x.ld % 32 || ((uintptr_t)a.x.p & 127))) fail("conv: H16 input needs 32-channel granularity");
     if (a.y.fmt == FMT_H16 && (a.y.c % 32 || a.y.ld % 32 || ((uintptr_t)a.y.p & 127))) fail("conv: H16 output needs 32-channel granularity");
     if (a.x.c % 4 || a.x.ld % 4 || ((uintptr_t)a.x.p & 15)) fail("conv: input channels/stride must be multiples of 4 (got c=%d ld=%d)", a.x.c, a.x.ld);
@@ -343,7 +344,7 @@ static std::string tune_key(const ConvArgs &a) {
         while (p2 * 2 <= n) p2 *= 2;
         n = n >= p2 + p2 / 2 ? p2 + p2 / 2 : p2;
     }
-    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d", conv_math(), n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
+    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d", conv_math() + (a.terms == 1 ? 10 : 0), n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
              a.y.h, a.y.w, a.ksize, a.stride, a.act, a.res.p ? a.res_mode : 0, a.x.fmt, a.y.fmt);
     return buf;
 }

@@ -29,6 +29,7 @@ struct ConvKernelArgs {
     int K, Kpad, M;
     int act, res_mode;
     int fmt_x, fmt_y, fmt_r;              // TensorFmt of input, output and residual views
+    int terms;                            // 3: f16x3, 1: hi halves only (half mode; LDS-DMA and window kernels)
     // XCD-aware tile map: the 8 XCDs own an xm x xn grid of rectangles of rm x rn tiles (workgroup id % 8 = XCD)
     int tiles_m, tiles_n, xm, rm, rn;
 };

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
 
 constexpr int ZERO_PAGE_BYTES = 64 * 1024;                      // >= Cin * 4 + 128 for every layer (checked at launch)
 
-template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES>
+template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(WM * WN * 64, (NS * (BM + BN) * 128 <= 80 * 1024 && WM * WN == 4) ? 2 : 1)
 void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -368,11 +368,13 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     h8 fr[2][NF];                                               // [substep][ah.., al.., bh.., bl..]
     auto frag_read = [&](const char *st, int s, int f) {
         const int which = f / 2, lo = f & 1;                    // f = 2*tile + (hi|lo), A tiles first
+        if (TERMS == 1 && lo) return;                           // half mode: hi halves only
         const int off = which < TM ? a_frag + which * 32 * ROW : b_frag + (which - TM) * 32 * ROW;
         fr[s][f] = *reinterpret_cast<const h8 *>(st + off + (lo ? pos_lo[s] : pos_hi[s]));
     };
     auto mfma = [&](int s, int m) {
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
+        if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
         else if (term == 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[i][j], 0, 0, 0);
@@ -445,7 +447,8 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
+            for (int e = 0; e < 16; ++e)
+                acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     static_assert((BM / WM) * (BN + 4) * 4 <= NS * STAGE, "epilogue staging must fit the ring");
     conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT>(p, acc1, reinterpret_cast<float *>(ring), m0, n0, tid);
 }
@@ -459,10 +462,10 @@ static const char *zero_page_dev() {
     return static_cast<const char *>(z);
 }
 
-template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES> static void launch_inst_dma(ConvKernelArgs k, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS> static void launch_inst_dma(ConvKernelArgs k, hipStream_t s) {
     constexpr size_t smem = (size_t)NS * (BM + BN) * 128;
     static bool attr_set = false;
-    auto kern = conv_igemm_f16x3_dma<BM, BN, WM, WN, NS, ACT, RES>;
+    auto kern = conv_igemm_f16x3_dma<BM, BN, WM, WN, NS, ACT, RES, TERMS>;
     if (!attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
@@ -475,7 +478,13 @@ template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES> static void 
 template <int BM, int BN, int WM, int WN, int NS> static void launch_cfg_dma(const ConvKernelArgs &k, hipStream_t s) {
     if (k.fmt_x != FMT_H16 || k.Cin % 32) fail("conv: the LDS-DMA kernel needs a pre-split (H16) input");
     if ((size_t)k.Cin * 4 + 128 > (size_t)ZERO_PAGE_BYTES) fail("conv: %d input channels exceed the zero page of the LDS-DMA kernel", k.Cin);
-#define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R>(k, s)
+    if (k.terms == 1) {
+#define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R, 1>(k, s)
+        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        return;
+    }
+#define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R, 3>(k, s)
     YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
 }

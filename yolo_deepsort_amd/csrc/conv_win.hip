@@ -32,7 +32,9 @@ constexpr int APW = 7;                         // window DMA instructions per wa
 constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 
 // BN x (WM x WN waves): 128 x (4x2) = 64x64 accumulator tiles per wave; 64 x (8x1) / 64 x (4x2) for 64-filter layers
-template <int BN, int WM, int WN, int ACT, int RES>
+// TERMS: 3 = f16x3; 1 = half mode (hi halves of both operands only: no lo fragment reads, one MFMA per product block -
+// compile-time pruning of the same pinned slot plan)
+template <int BN, int WM, int WN, int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows, int nbuf) {
     static_assert(WM * WN == NW, "eight waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     int a_addr[TM], a_sw[TM];                                   // this tap: LDS byte address of the lane's window row (or the zero row), swizzle
     auto frag_read = [&](const char *bst, int s, int f) {
         const int which = f / 2, lo = f & 1;
+        if (TERMS == 1 && lo) return;
         if (which < TM) {
             const int c = (lo ? 4 : 0) + 2 * s + kb;
             fr[s][f] = *reinterpret_cast<const h8 *>(smem + a_addr[which] + ((c ^ a_sw[which]) << 4));
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     };
     auto mfma = [&](int s, int m) {
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
+        if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
         if (YDS_WIN_ABL == 3) { acc1[i][j][term] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3]; return; }
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
@@ -238,17 +242,18 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
+            for (int e = 0; e < 16; ++e)
+                acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);
 }
 
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
 
-template <int BN, int WM, int WN, int ACT, int RES> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
+template <int BN, int WM, int WN, int ACT, int RES, int TERMS = 3> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
     const int wrows = window_rows(k.W), nbuf = k.Cin == 32 ? 1 : 2;
     const size_t smem = (size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW;
     static size_t attr_set = 0;
-    auto kern = conv3x3_f16x3_win<BN, WM, WN, ACT, RES>;
+    auto kern = conv3x3_f16x3_win<BN, WM, WN, ACT, RES, TERMS>;
     if (smem > attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = smem;
@@ -272,7 +277,17 @@ bool conv_win_applicable(const ConvKernelArgs &k) {
 
 void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
     if (!conv_win_applicable(k)) fail("conv: the window-resident kernel needs a 3x3 stride-1 layer with a pre-split input and W <= 95 (W <= 318 for 32 input channels)");
-    if (shape == 0) {
+    if (k.terms == 1) {                                          // half mode: one instantiation family (256x128, or 256x64 for narrow layers)
+        if (shape == 0) {
+#define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R, 1>(k, s)
+            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        } else {
+#define YDS_CALL(A, R) launch_inst_win<64, 4, 2, A, R, 1>(k, s)
+            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        }
+    } else if (shape == 0) {
 #define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL

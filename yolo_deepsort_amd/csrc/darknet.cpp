@@ -411,6 +411,7 @@ ConvArgs Darknet::conv_args(int i, int batch) const {
     a.ksize = l.ksize; a.stride = l.stride; a.pad = l.pad; a.kpad = l.kpad;
     a.act = l.act;
     if (l.fused_res >= 0) { a.res = view(l.fused_res, batch); a.res_mode = RES_AFTER_ACT; }
+    a.terms = half_mode ? 1 : 3;
     return a;
 }
 
@@ -418,10 +419,11 @@ void Darknet::autotune(int batch) {
     static const bool off = getenv("YDS_NO_AUTOTUNE") != nullptr;
     for (int i = 0; i < (int)layers.size(); ++i) {
         Layer &l = layers[i];
-        if (l.type != "convolutional" || !l.loaded || (l.tuned_batch == batch && l.tuned_math == conv_math())) continue;
+        const int mode = conv_math() + (half_mode ? 10 : 0);
+        if (l.type != "convolutional" || !l.loaded || (l.tuned_batch == batch && l.tuned_math == mode)) continue;
         l.variant = off ? -1 : conv_autotune(conv_args(i, batch), stream, nullptr);
         l.tuned_batch = batch;
-        l.tuned_math = conv_math();
+        l.tuned_math = mode;
     }
 }
 
@@ -593,7 +595,7 @@ void Darknet::forward_tiles_host(const uint8_t *frame, int h, int w, const int *
 
 bool Darknet::stem_fused(int batch) {
     static const bool off = getenv("YDS_NO_STEM_FUSE") != nullptr;
-    if (off || !stem_fusable || conv_math() != MATH_F16X3 || !layers[0].loaded || !layers[1].loaded) return false;
+    if (off || half_mode || !stem_fusable || conv_math() != MATH_F16X3 || !layers[0].loaded || !layers[1].loaded) return false;
     if (stem_checked != batch) {
         ConvArgs a0 = conv_args(0, batch), a1 = conv_args(1, batch);
         stem_ok = a1.w16 && a1.y.fmt == FMT_H16 && conv_stem2_applicable(make_conv_args(a0), make_conv_args(a1));
@@ -604,7 +606,7 @@ bool Darknet::stem_fused(int batch) {
 
 bool Darknet::block1_fused(int batch) {
     static const bool off = getenv("YDS_NO_BLOCK_FUSE") != nullptr;
-    if (off || block1_at < 0 || conv_math() != MATH_F16X3 || !layers[block1_at].loaded || !layers[block1_at + 1].loaded) return false;
+    if (off || half_mode || block1_at < 0 || conv_math() != MATH_F16X3 || !layers[block1_at].loaded || !layers[block1_at + 1].loaded) return false;
     if (block1_checked != batch) {
         ConvArgs a2 = conv_args(block1_at, batch), a3 = conv_args(block1_at + 1, batch);
         block1_ok = a2.w16 && a3.w16 && conv_block1_applicable(make_conv_args(a2), make_conv_args(a3));
@@ -715,6 +717,13 @@ int yds_darknet_set_batch_max(yds_net *n, int batch_max) {
     YDS_API_END
 }
 int yds_darknet_batch_max(const yds_net *n) { return n->d->batch_max; }
+int yds_darknet_set_half(yds_net *n, int on) {
+    YDS_API_BEGIN
+    if (on && n->d->math != yds::MATH_F16X3) yds::fail("half mode needs the split-fp16 tensor formats (conv math f16x3)");
+    n->d->half_mode = on != 0;
+    n->d->stem_checked_reset();
+    YDS_API_END
+}
 int yds_darknet_num_boxes(const yds_net *n) { return n->d->total_boxes; }
 int yds_darknet_num_attrs(const yds_net *n) { return n->d->attrs; }
 int yds_darknet_num_layers(const yds_net *n) { return (int)n->d->layers.size(); }

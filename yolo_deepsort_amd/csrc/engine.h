@@ -76,6 +76,8 @@ public:
 
     int img_h, img_w, batch_max, in_channels = 3;
     int math = 0;                            // conv arithmetic the plan (tensor formats) was built for
+    bool half_mode = false;                  // Darknet.half(): single-term fp16 operands in the LDS-DMA / window kernels
+    void stem_checked_reset() { stem_checked = block1_checked = -1; }
     int total_boxes = 0, attrs = 0;
     std::vector<Layer> layers;
     std::vector<Storage> storage;
@@ -202,6 +204,10 @@ struct TrackerIface {
     // feats: [D,512] on device when feats_on_device, else host.  Returns rows written to out6 (int32 [m,6]).
     virtual int step(const float *tlwh_host, const float *feats, bool feats_on_device, const float *payload_host, int D,
                      int32_t *out6_host, int cap) = 0;
+    // the frames of one batch in order with ONE host synchronisation: detections of frame b are rows [first[b], first[b+1])
+    // of tlwh / feats_dev / payload; skip[b] != 0: tracker not called for that frame (counts[b] = -1)
+    virtual void step_batch(int n, const float *tlwh_host, const int *first, const float *feats_dev, const float *payload_host, const char *skip,
+                            int32_t *out6_host, int cap, int32_t *counts) = 0;
     virtual int num_tracks() const = 0;
 };
 

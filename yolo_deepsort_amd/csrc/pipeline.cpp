@@ -188,12 +188,10 @@ public:
             in_flight = nullptr;
             launch_reid(ahead, h, w);
         }
-        for (int b = 0; b < batch; ++b) {
-            if (cur.n_det[b] == 0) { counts[b] = -1; continue; }       // detector returned None: tracker not called
-            const int D = cur.first[b + 1] - cur.first[b];
-            counts[b] = trk->step(cur.tlwh.data() + (size_t)cur.first[b] * 4, feat_cur.p + (size_t)cur.first[b] * 512, true,
-                                  cur.payload.data() + cur.first[b], D, out6 + (size_t)b * cap * 6, cap);
-        }
+        // association of the whole batch, frame after frame on the tracker's stream, one host synchronisation
+        std::vector<char> skip(batch, 0);
+        for (int b = 0; b < batch; ++b) skip[b] = cur.n_det[b] == 0;  // detector returned None: tracker not called (video_detect.py:137)
+        trk->step_batch(batch, cur.tlwh.data(), cur.first.data(), feat_cur.p, cur.payload.data(), skip.data(), out6, cap, counts);
         auto t_end = clk::now();
         stage_us[2] = us(t_begin, t_nms); stage_us[3] = us(t_nms, t_reid); stage_us[4] = us(t_reid, t_end);
     }

@@ -7,10 +7,12 @@
 //   iou / iou_cost                                                   deep_sort/sort/iou_matching.py:5-91
 //   scipy.optimize.linear_sum_assignment (third party)               call site linear_assignment.py:56
 //   DeepSort.update output stage                                     deep_sort/deep_sort.py:63-88,108-114
-// Track state (mean, covariance, appearance gallery ring) lives in HBM, addressed through slot ids;
-// integer lifecycle state (ids, hits, age, time_since_update, Tentative/Confirmed/Deleted) and the
-// order-sensitive list bookkeeping (linear_assignment.py:58-72, tracker.py:56-93,115-176, track.py) stay
-// on the host: they are a few hundred integer operations per frame and decide track ids.
+// ALL track state lives in HBM: mean, covariance and the appearance gallery ring by slot id, and the integer lifecycle
+// table (ids, hits, age, time_since_update, Tentative/Confirmed/Deleted, ring position, payload) in track-list order.
+// The order-sensitive list bookkeeping (linear_assignment.py:58-72, tracker.py:56-93,115-176, track.py) runs in two
+// single-workgroup kernels built from ordered compactions (ballot + prefix), so a frame is a fixed sequence of launches
+// whose sizes are read from device memory: the host synchronises ONCE per frame - or once per batch of frames
+// (step_batch, used by the pipeline) - to fetch the int32 rows.
 #include "engine.h"
 
 #include <algorithm>
@@ -22,16 +24,12 @@ namespace yds {
 constexpr int EMB = 512;
 constexpr float INFTY_COST = 1e5f;
 constexpr float CHI2_2DOF = 5.9915f;
-constexpr int LSAP_MAX = 1024;
 
 // ------------------------------------------------------------------------------------------ Kalman
 // std weights are fp32 roundings of 1/20 and 1/160 like the reference's tensors (kalman_filter.py:39-52)
 __device__ __constant__ float kStdPos = 1.f / 20, kStdVel = 1.f / 160;
 
-__global__ void kf_predict_kernel(float *mean, float *cov, const int *slots, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float *m = mean + (size_t)slots[t] * 8, *P = cov + (size_t)slots[t] * 64;
+__device__ __forceinline__ void kf_predict_body(float *m, float *P) {
     const float h = m[3];
     float q[8];
     float sp = h * kStdPos, sv = h * kStdVel;
@@ -53,6 +51,11 @@ __global__ void kf_predict_kernel(float *mean, float *cov, const int *slots, int
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = m[i] + m[i + 4];
 }
+__global__ void kf_predict_kernel(float *mean, float *cov, const int *slots, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    kf_predict_body(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64);
+}
 
 __device__ __forceinline__ void project4(const float *m, const float *P, float S[4][4]) {
     float sp = m[3] * kStdPos;
@@ -64,10 +67,7 @@ __device__ __forceinline__ void project4(const float *m, const float *P, float S
 }
 
 // z: xyah per match; solves S K^T = (P H)^T by LU with partial pivoting, then the K S K^T form
-__global__ void kf_update_kernel(float *mean, float *cov, const int *slots, const float *z, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float *m = mean + (size_t)slots[t] * 8, *P = cov + (size_t)slots[t] * 64;
+__device__ __forceinline__ void kf_update_body(float *m, float *P, const float *zt) {
     float S[4][4], LU[4][4], Kt[4][8];
     project4(m, P, S);
     int piv[4] = {0, 1, 2, 3};
@@ -104,7 +104,7 @@ __global__ void kf_update_kernel(float *mean, float *cov, const int *slots, cons
     }
     float innov[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) innov[i] = z[t * 4 + i] - m[i];
+    for (int i = 0; i < 4; ++i) innov[i] = zt[i] - m[i];
     float KS[8][4];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
@@ -132,13 +132,14 @@ __global__ void kf_update_kernel(float *mean, float *cov, const int *slots, cons
         m[j] = m[j] + v;
     }
 }
-
-// new tracks from detections (kalman_filter.py:54-87 + detection.py:41-48)
-__global__ void kf_initiate_kernel(float *mean, float *cov, const int *slots, const float *tlwh, const int *det_idx, int n) {
+__global__ void kf_update_kernel(float *mean, float *cov, const int *slots, const float *z, int n) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    const float *b = tlwh + (size_t)det_idx[t] * 4;
-    float *m = mean + (size_t)slots[t] * 8, *P = cov + (size_t)slots[t] * 64;
+    kf_update_body(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64, z + t * 4);
+}
+
+// new tracks from detections (kalman_filter.py:54-87 + detection.py:41-48)
+__device__ __forceinline__ void kf_initiate_body(float *m, float *P, const float *b) {
     float w = b[2], h = b[3];
     float cx = b[0] + w / 2.f, cy = b[1] + h / 2.f, a = w / h;
     m[0] = cx; m[1] = cy; m[2] = a; m[3] = h; m[4] = m[5] = m[6] = m[7] = 0.f;
@@ -147,6 +148,11 @@ __global__ void kf_initiate_kernel(float *mean, float *cov, const int *slots, co
     float d[8] = {sp * sp, sp * sp, 1e-2f * 1e-2f, sp * sp, sv * sv, sv * sv, 1e-5f * 1e-5f, sv * sv};
     for (int i = 0; i < 64; ++i) P[i] = 0.f;
     for (int i = 0; i < 8; ++i) P[i * 9] = d[i];
+}
+__global__ void kf_initiate_kernel(float *mean, float *cov, const int *slots, const float *tlwh, const int *det_idx, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    kf_initiate_body(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64, tlwh + (size_t)det_idx[t] * 4);
 }
 
 __device__ __forceinline__ void to_xyah(const float *b, float z[4]) {
@@ -197,14 +203,18 @@ __global__ void normalize_rows_kernel(const float *src, const int *src_idx, floa
     for (int k = 0; k < EMB / 64; ++k) dst[(size_t)row * EMB + lane + 64 * k] = v[k] / nrm;
 }
 
+// Track rows are named either directly (slots / n_rows, the stand-alone entry) or through the device-resident track table:
+// row t = track idx[t] of the table (tab_slot / tab_nfeat), t < *count_p (device-side count; surplus blocks return).
 __global__ __launch_bounds__(256) void appearance_cost_kernel(const float *gallery_n, const int *slots, const int *n_rows, int budget,
                                                              const float *feats_n, int D, const float *mean, const float *cov,
-                                                             const float *tlwh, float max_dist, float flood, int do_gate, int euclid, float *cost) {
+                                                             const float *tlwh, float max_dist, float flood, int do_gate, int euclid, float *cost,
+                                                             const int *idx, const int *tab_slot, const int *tab_nfeat, const int *count_p) {
     __shared__ float fs[16][EMB + 1], gs[16][EMB + 1];
     __shared__ float best[16][17];
     const int t = blockIdx.x, d0 = blockIdx.y * 16;
+    if (count_p && t >= *count_p) return;
     const int nd = min(16, D - d0);
-    const int slot = slots[t], rows = n_rows[t];
+    const int slot = idx ? tab_slot[idx[t]] : slots[t], rows = idx ? tab_nfeat[idx[t]] : n_rows[t];
     for (int i = threadIdx.x; i < 16 * (EMB / 4); i += blockDim.x) {        // detection slab, float4 coalesced
         const int d = i / (EMB / 4), k4 = i % (EMB / 4);
         float4 v = d < nd ? *reinterpret_cast<const float4 *>(feats_n + (size_t)(d0 + d) * EMB + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,12 +263,15 @@ __global__ __launch_bounds__(256) void appearance_cost_kernel(const float *galle
 }
 
 // ------------------------------------------------------------------------------------------ IOU cost
+// dims_p (optional): device-side {T, D}; cand / tab_slot / tab_tsu (optional): row t = track cand[t] of the track table
 __global__ void iou_cost_kernel(const float *mean, const int *slots, const int *stale, int T, const float *tlwh, const int *det_idx,
-                                int D, float max_dist, float flood, float *cost) {
+                                int D, float max_dist, float flood, float *cost, const int *dims_p, const int *cand, const int *tab_slot,
+                                const int *tab_tsu) {
+    if (dims_p) { T = dims_p[0]; D = dims_p[1]; }
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T * D) return;
     int t = idx / D, d = idx - t * D;
-    const float *m = mean + (size_t)slots[t] * 8;
+    const float *m = mean + (size_t)(cand ? tab_slot[cand[t]] : slots[t]) * 8;
     float bw = m[2] * m[3], bh = m[3];                        // Track.to_tlwh track.py:81-94
     float bx = m[0] - bw / 2.f, by = m[1] - bh / 2.f;
     const float *c = tlwh + (size_t)det_idx[d] * 4;
@@ -267,102 +280,111 @@ __global__ void iou_cost_kernel(const float *mean, const int *slots, const int *
     float iw = fmaxf(ix1 - ix0 + 1.f, 0.f), ih = fmaxf(iy1 - iy0 + 1.f, 0.f);      // asymmetric +1, iou_matching.py:36
     float inter = iw * ih;
     float v = 1.f - inter / (bw * bh + c[2] * c[3] - inter);
-    if (stale && stale[t]) v = INFTY_COST;                    // time_since_update > 1, iou_matching.py:86-89
+    if (cand ? tab_tsu[cand[t]] > 1 : (stale && stale[t])) v = INFTY_COST;      // time_since_update > 1, iou_matching.py:86-89
     if (max_dist > 0.f && v > max_dist) v = flood;
     cost[idx] = v;
 }
 
 // ------------------------------------------------------------------------------------------ LSAP
-// scipy.optimize.linear_sum_assignment (rectangular_lsap.cpp, Crouse 2016) on ONE wavefront: the
-// augmenting-path search is sequential over rows, its column scan is spread over the 64 lanes and the
-// sequential tie-break of the scalar scan is reproduced exactly:
-//   index = last unassigned column (in `remaining` order) among the minimum, else the first minimum.
-// Arithmetic is fp64 in the same order as scipy (minVal + c - u[i] - v[j]).  Tall matrices are solved
-// transposed.  row_out/col_out: min(nr,nc) pairs sorted by row.
-__device__ __forceinline__ double wave_min(double v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_min_i(int v) {
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
+// scipy.optimize.linear_sum_assignment (rectangular_lsap.cpp, Crouse 2016) on ONE workgroup of four wavefronts.  The
+// augmenting-path search is sequential over rows; its column scan is spread over 256 lanes and the sequential tie-break of
+// the scalar scan is reproduced exactly:
+//   index = last unassigned column (in `remaining` order) among the minimum, else the first minimum
+// encoded as a key so that ONE lexicographic (cost, key) reduction per Dijkstra step finds it.  Arithmetic is fp64 in the
+// same order as scipy (minVal + c - u[i] - v[j]).  Tall matrices are solved transposed.  Position `it` of `remaining` is
+// always scanned - and rewritten - by thread it % 256, the winner's column travels with the reduction, and the per-wave
+// partial results are double buffered, so a Dijkstra step costs one barrier.  Solver state lives in LDS (and the cost
+// matrix too when it fits); beyond ~3000 rows/columns it moves to a global scratch buffer - no size limit.
+// dims_p (optional): device-side {nr, nc}.  row_out/col_out: min(nr,nc) pairs sorted by row, *n_out = that count.
+constexpr int LSAP_NT = 256, LSAP_NW = LSAP_NT / 64;
+constexpr size_t LSAP_STATE_BYTES = 3 * sizeof(double) + 6 * sizeof(int);      // per row / column
+constexpr size_t LSAP_LDS_MAX = 150 * 1024;
 
-__global__ __launch_bounds__(64) void lsap_kernel(const float *cost, int nr0, int nc0, int *row_out, int *col_out, int cost_in_lds) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr0, int nc0, const int *dims_p, int *row_out, int *col_out,
+                                                       int *n_out, int cost_in_lds, char *state_global) {
+    if (dims_p) { nr0 = dims_p[0]; nc0 = dims_p[1]; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (nr0 <= 0 || nc0 <= 0) {                                  // linear_assignment.py:48-49 early-out
+        if (tid == 0 && n_out) *n_out = 0;
+        return;
+    }
     const bool transpose = nc0 < nr0;
     const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
-    // all solver state lives in LDS; when it fits, so does the cost matrix (the augmenting-path scan is a chain of
-    // dependent lookups: one L2 round trip per Dijkstra step was most of the kernel's time)
     extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
+    __shared__ double red_val[2][LSAP_NW];
+    __shared__ int red_key[2][LSAP_NW], red_col[2][LSAP_NW];
     const int n = max(nr, nc);
-    double *u = reinterpret_cast<double *>(lsap_smem), *v = u + n, *spc = v + n;
+    char *base = state_global ? state_global : lsap_smem;
+    double *u = reinterpret_cast<double *>(base), *v = u + n, *spc = v + n;
     int *path = reinterpret_cast<int *>(spc + n), *col4row = path + n, *row4col = col4row + n, *remaining = row4col + n, *SR = remaining + n,
         *SC = SR + n;
-    float *cost_lds = reinterpret_cast<float *>(SC + n);
+    float *cost_lds = reinterpret_cast<float *>(lsap_smem + (state_global ? 0 : (size_t)n * LSAP_STATE_BYTES));
     if (cost_in_lds) {
-        for (int i = lane; i < nr0 * nc0; i += 64) cost_lds[i] = cost[i];
-        __syncthreads();
+        for (int i = tid; i < nr0 * nc0; i += LSAP_NT) cost_lds[i] = cost[i];
     }
     const float *cm = cost_in_lds ? cost_lds : cost;
     auto C = [&](int i, int j) -> double { return (double)(transpose ? cm[(size_t)j * nc0 + i] : cm[(size_t)i * nc0 + j]); };
-    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
-    for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
+    for (int i = tid; i < nr; i += LSAP_NT) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = tid; j < nc; j += LSAP_NT) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
     __syncthreads();
+    int parity = 0;
     for (int cur = 0; cur < nr; ++cur) {
-        for (int i = lane; i < nr; i += 64) SR[i] = 0;
-        for (int j = lane; j < nc; j += 64) { SC[j] = 0; spc[j] = INFINITY; remaining[j] = nc - j - 1; }
+        for (int i = tid; i < nr; i += LSAP_NT) SR[i] = 0;
+        for (int j = tid; j < nc; j += LSAP_NT) { SC[j] = 0; spc[j] = INFINITY; remaining[j] = nc - j - 1; }   // position it <-> thread it % 256
         __syncthreads();
         double minVal = 0.0;
         int num_remaining = nc, i = cur, sink = -1;
         while (sink == -1) {
-            if (lane == 0) SR[i] = 1;
+            if (tid == 0) SR[i] = 1;
             const double ui = u[i];
-            // one pass, one reduction: the candidate is the lexicographic minimum of (shortest path cost, key) where the key
-            // encodes scipy's tie-break - among equal costs the LAST unassigned column in `remaining` order, otherwise the
-            // FIRST column: unassigned -> 0x3fffffff - it (larger it = smaller key), assigned -> 0x40000000 + it
+            // candidate = lexicographic minimum of (shortest path cost, key): among equal costs the LAST unassigned column in
+            // `remaining` order, otherwise the FIRST column: unassigned -> 0x3fffffff - it, assigned -> 0x40000000 + it
             double lmin = INFINITY;
-            int lkey = 0x7fffffff;
-            for (int it = lane; it < num_remaining; it += 64) {
-                int j = remaining[it];
-                double r = minVal + C(i, j) - ui - v[j];
-                double s = spc[j];
-                if (r < s) { path[j] = i; spc[j] = r; s = r; }
+            int lkey = 0x7fffffff, lcol = -1;
+            for (int it = tid; it < num_remaining; it += LSAP_NT) {
+                const int j = remaining[it];
+                const double r = minVal + C(i, j) - ui - v[j];
+                double sv = spc[j];
+                if (r < sv) { path[j] = i; spc[j] = r; sv = r; }
                 const int key = row4col[j] == -1 ? 0x3fffffff - it : 0x40000000 + it;
-                if (s < lmin || (s == lmin && key < lkey)) { lmin = s; lkey = key; }
+                if (sv < lmin || (sv == lmin && key < lkey)) { lmin = sv; lkey = key; lcol = j; }
             }
             for (int o = 32; o > 0; o >>= 1) {
                 const double os = __shfl_xor(lmin, o, 64);
-                const int ok = __shfl_xor(lkey, o, 64);
-                if (os < lmin || (os == lmin && ok < lkey)) { lmin = os; lkey = ok; }
+                const int ok = __shfl_xor(lkey, o, 64), oc = __shfl_xor(lcol, o, 64);
+                if (os < lmin || (os == lmin && ok < lkey)) { lmin = os; lkey = ok; lcol = oc; }
             }
-            const double lowest = lmin;
+            if (lane == 0) { red_val[parity][wave] = lmin; red_key[parity][wave] = lkey; red_col[parity][wave] = lcol; }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < LSAP_NW; ++w) {
+                const double os = red_val[parity][w];
+                const int ok = red_key[parity][w];
+                if (os < lmin || (os == lmin && ok < lkey)) { lmin = os; lkey = ok; lcol = red_col[parity][w]; }
+            }
+            parity ^= 1;
+            minVal = lmin;
             const int index = lkey < 0x40000000 ? 0x3fffffff - lkey : lkey - 0x40000000;
-            minVal = lowest;
-            const int j = remaining[index];
+            const int j = lcol;
             const int owner = row4col[j];
             if (owner == -1) sink = j; else i = owner;
-            __syncthreads();
-            if (lane == 0) {
+            // swap-with-last removal, done by the thread that owns position `index` (the only future reader of it)
+            if (tid == (index & (LSAP_NT - 1))) {
                 SC[j] = 1;
                 remaining[index] = remaining[num_remaining - 1];
             }
             --num_remaining;
-            __syncthreads();
         }
+        __syncthreads();
         // dual update
-        for (int r = lane; r < nr; r += 64) {
+        for (int r = tid; r < nr; r += LSAP_NT) {
             if (r == cur) u[r] += minVal;
             else if (SR[r]) u[r] += minVal - spc[col4row[r]];
         }
-        for (int j = lane; j < nc; j += 64)
+        for (int j = tid; j < nc; j += LSAP_NT)
             if (SC[j]) v[j] -= minVal - spc[j];
         __syncthreads();
-        if (lane == 0) {
+        if (tid == 0) {
             int j = sink;
             while (true) {
                 int r = path[j];
@@ -373,55 +395,40 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float *cost, int nr0, in
         }
         __syncthreads();
     }
-    if (lane == 0) {
-        if (transpose) {
+    if (transpose) {
+        if (tid == 0) {
             int k = 0;
             for (int r = 0; r < nc; ++r) {          // nc == original row count
                 int who = row4col[r];
                 if (who >= 0) { row_out[k] = r; col_out[k] = who; ++k; }
             }
-        } else {
-            for (int r = 0; r < nr; ++r) { row_out[r] = r; col_out[r] = col4row[r]; }
         }
+    } else {
+        for (int r = tid; r < nr; r += LSAP_NT) { row_out[r] = r; col_out[r] = col4row[r]; }
     }
+    if (tid == 0 && n_out) *n_out = nr;
 }
 
-static void launch_lsap(const float *cost_dev, int nr, int nc, int *rows_dev, int *cols_dev, hipStream_t s) {
-    const int n = nr > nc ? nr : nc;
-    size_t state = (size_t)n * (3 * sizeof(double) + 6 * sizeof(int)), with_cost = state + (size_t)nr * nc * sizeof(float);
-    const bool in_lds = with_cost <= 150 * 1024;
-    const size_t smem = in_lds ? with_cost : state;
+// nr_max / nc_max: upper bounds known on the host (they size the LDS / scratch); the real sizes may come from dims_dev
+static void launch_lsap(const float *cost_dev, int nr_max, int nc_max, const int *dims_dev, int *rows_dev, int *cols_dev, int *n_out_dev,
+                        DevBuf<char> &scratch, hipStream_t s) {
+    const size_t n = (size_t)std::max(std::max(nr_max, nc_max), 1);
+    const size_t state = n * LSAP_STATE_BYTES, cost_bytes = (size_t)nr_max * nc_max * sizeof(float);
+    const bool state_lds = state <= LSAP_LDS_MAX;
+    const bool cost_lds = (state_lds ? state : 0) + cost_bytes <= LSAP_LDS_MAX;
+    const size_t smem = (state_lds ? state : 0) + (cost_lds ? cost_bytes : 0);
+    if (!state_lds && scratch.n < state) {
+        YDS_HIP(hipStreamSynchronize(s));                        // nothing may still use the old scratch
+        scratch.alloc(state);
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(64), smem, s, cost_dev, nr, nc, rows_dev, cols_dev, in_lds ? 1 : 0);
+    hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(LSAP_NT), smem, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev, n_out_dev,
+                       cost_lds ? 1 : 0, state_lds ? (char *)nullptr : scratch.p);
     YDS_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------------------ misc
-// appends the (already normalised) detection feature det_idx[t] to the gallery ring of slot slots[t]
-__global__ void feature_append_kernel(float *gallery_n, int budget, const int *slots, const int *pos, const float *feats_n, const int *det_idx,
-                                      int n) {
-    int t = blockIdx.x;
-    if (t >= n) return;
-    float *dst = gallery_n + ((size_t)slots[t] * budget + pos[t]) * EMB;
-    const float *src = feats_n + (size_t)det_idx[t] * EMB;
-    for (int k = threadIdx.x; k < EMB; k += blockDim.x) dst[k] = src[k];
-}
-
-// deep_sort.py:73-87: w = a*h; xy -= wh/2; x2y2 = wh + xy; x1y1 = max(.,0); int32 truncation
-__global__ void output_kernel(const float *mean, const int *slots, const int *ids, const float *payload, int n, int *out6) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const float *m = mean + (size_t)slots[t] * 8;
-    float w = m[2] * m[3], h = m[3];
-    float x = m[0] - w / 2.f, y = m[1] - h / 2.f;
-    float x2 = w + x, y2 = h + y;
-    x = fmaxf(x, 0.f); y = fmaxf(y, 0.f);
-    int *o = out6 + t * 6;
-    o[0] = (int)x; o[1] = (int)y; o[2] = (int)x2; o[3] = (int)y2; o[4] = ids[t]; o[5] = (int)payload[t];
 }
 
 // ------------------------------------------------------------------------------- tracker-side NMS
@@ -459,110 +466,466 @@ __global__ __launch_bounds__(256) void tracker_nms_kernel(const float *tlwh, con
     if (threadIdx.x == 0) *n_pick = count;
 }
 
-// ============================================================================================ host
+// ============================================================================================ device-resident tracker
 enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
 enum { METRIC_COSINE = 0, METRIC_EUCLIDEAN = 1 };
 
-struct Track {
-    int slot, id, hits = 1, age = 1, tsu = 0, state = TENTATIVE;
-    int n_feat = 0, head = 0;        // gallery ring fill / next write position
-    float payload = 0.f;
+// Integer lifecycle table, one entry per track in track-list order (deep_sort/sort/track.py:63-79), in device memory.
+struct TrackTable {
+    int *slot, *id, *hits, *age, *tsu, *state, *n_feat, *head;
+    float *payload;
+};
+constexpr int TAB_FIELDS = 9;
+
+// device-side counters of one frame (ints)
+enum Meta {
+    M_T = 0,        // live tracks
+    M_NEXT_ID,      // Tracker._next_id (tracker.py:47)
+    M_NFREE,        // free gallery / Kalman slots
+    M_TC, M_D,      // confirmed tracks, detections      (stage A problem: dims at &meta[M_TC])
+    M_TB, M_DB,     // IOU-stage candidates, leftover detections (stage B problem: dims at &meta[M_TB])
+    M_NA, M_NB,     // assigned pairs returned by the two LSAP solves
+    M_NM_A,         // matches of stage A
+    M_NUT_A,        // unmatched confirmed tracks of stage A
+    M_NKEEP,        // of those, not eligible for the IOU stage
+    M_NM,           // matches (both stages)
+    M_NUT,          // unmatched tracks (final)
+    M_NUD,          // unmatched detections (final) = new tracks
+    M_NOUT,         // output rows
+    M_COUNT = 16
 };
 
+struct TrkDev {
+    TrackTable tab, tmp;
+    int *meta, *free_slots;
+    float *mean, *cov, *gallery, *feats_n, *cost;
+    const float *tlwh, *payload;                    // this frame's detections
+    int *conf_idx, *unconf_idx, *rows, *cols, *flag_r, *flag_c, *rej;
+    int *matches, *um_t_a, *um_t_keep, *um_t, *um_d, *um_d2, *iou_cand;
+    int *upd_slot, *upd_det, *upd_pos, *new_slot, *out_slot, *out_id;
+    float *out_payload;
+    int budget, unbounded, n_init, max_age;
+    float max_dist, max_iou;
+    // per-frame result block (device copy of what goes back to the host): header, rows, debug lists
+    int *res;
+    int res_out6, res_matches, res_um_t, res_um_d;   // int offsets inside res
+};
+
+// ordered compaction over [0, n) by a 256-thread workgroup: emit(i, rank) for every i with pred(i), ranks ascending
+// with i; returns the number of hits (to every thread).  s_cnt: LDS int[4].
+template <class Pred, class Emit> __device__ __forceinline__ int compact_ordered(int n, int *s_cnt, Pred pred, Emit emit) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int total = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        const bool p = i < n && pred(i);
+        const unsigned long long b = __ballot(p);
+        const int lane_rank = __popcll(b & ((1ull << lane) - 1ull)), wave_cnt = __popcll(b);
+        if (lane == 0) s_cnt[wave] = wave_cnt;
+        __syncthreads();
+        int woff = 0, chunk = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const int c = s_cnt[w]; if (w < wave) woff += c; chunk += c; }
+        if (p) emit(i, total + woff + lane_rank);
+        __syncthreads();
+        total += chunk;
+    }
+    return total;
+}
+
+// Tracker.predict bookkeeping (track.py:110-123: age += 1, time_since_update += 1) and the confirmed / unconfirmed index
+// lists of Tracker._match (tracker.py:65-67), in list order.
+__global__ __launch_bounds__(256) void trk_begin_kernel(TrkDev d, int D) {
+    __shared__ int s_cnt[4];
+    const int T = d.meta[M_T];
+    for (int t = threadIdx.x; t < T; t += 256) { d.tab.age[t]++; d.tab.tsu[t]++; }
+    __syncthreads();
+    const int Tc = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] == CONFIRMED; }, [&](int t, int r) { d.conf_idx[r] = t; });
+    const int Tu = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] != CONFIRMED; }, [&](int t, int r) { d.unconf_idx[r] = t; });
+    if (threadIdx.x == 0) { d.meta[M_TC] = Tc; d.meta[M_D] = D; d.meta[M_TB] = Tu; }      // M_TB holds the unconfirmed count until stage A adds to it
+}
+
+__global__ void trk_predict_kernel(TrkDev d) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= d.meta[M_T]) return;
+    const int slot = d.tab.slot[t];
+    kf_predict_body(d.mean + (size_t)slot * 8, d.cov + (size_t)slot * 64);
+}
+
+// min_cost_matching list bookkeeping (linear_assignment.py:58-72) for one solved assignment problem:
+//   unmatched detections = [columns not assigned, ascending] then [rejected pairs in row order], unmatched tracks likewise,
+//   matches in row order; a pair is rejected when cost[row, col] > max_distance.
+// row_name(r) / col_name(c) translate problem rows / columns to track indices / detection indices.
+template <class RowName, class ColName>
+__device__ __forceinline__ void assign_lists(const TrkDev &d, int *s_cnt, int nr, int nc, int n_pairs, float max_distance, RowName row_name,
+                                             ColName col_name, int *matches, int &n_matches, int *um_t, int &n_um_t, int *um_d, int &n_um_d) {
+    const int tid = threadIdx.x;
+    for (int r = tid; r < nr; r += 256) d.flag_r[r] = 0;
+    for (int c = tid; c < nc; c += 256) d.flag_c[c] = 0;
+    __syncthreads();
+    for (int k = tid; k < n_pairs; k += 256) {
+        const int r = d.rows[k], c = d.cols[k];
+        d.flag_r[r] = 1;
+        d.flag_c[c] = 1;
+        d.rej[k] = d.cost[(size_t)r * nc + c] > max_distance ? 1 : 0;
+    }
+    __syncthreads();
+    const int d1 = compact_ordered(nc, s_cnt, [&](int c) { return d.flag_c[c] == 0; }, [&](int c, int q) { um_d[q] = col_name(c); });
+    const int d2 = compact_ordered(n_pairs, s_cnt, [&](int k) { return d.rej[k] != 0; }, [&](int k, int q) { um_d[d1 + q] = col_name(d.cols[k]); });
+    const int t1 = compact_ordered(nr, s_cnt, [&](int r) { return d.flag_r[r] == 0; }, [&](int r, int q) { um_t[q] = row_name(r); });
+    const int t2 = compact_ordered(n_pairs, s_cnt, [&](int k) { return d.rej[k] != 0; }, [&](int k, int q) { um_t[t1 + q] = row_name(d.rows[k]); });
+    const int nm = compact_ordered(n_pairs, s_cnt, [&](int k) { return d.rej[k] == 0; },
+                                   [&](int k, int q) { matches[2 * (n_matches + q)] = row_name(d.rows[k]); matches[2 * (n_matches + q) + 1] = col_name(d.cols[k]); });
+    n_um_d = d1 + d2;
+    n_um_t = t1 + t2;
+    n_matches += nm;
+}
+
+// after the appearance-stage assignment: its lists, then the IOU-stage candidates (tracker.py:80-85):
+// unconfirmed tracks (index order) + unmatched confirmed tracks with time_since_update == 1
+__global__ __launch_bounds__(256) void trk_match_a_kernel(TrkDev d) {
+    __shared__ int s_cnt[4];
+    const int Tc = d.meta[M_TC], D = d.meta[M_D], Tu = d.meta[M_TB];
+    const int n_pairs = (Tc > 0 && D > 0) ? d.meta[M_NA] : 0;              // either side empty: nothing was solved (linear_assignment.py:48-49)
+    int n_matches = 0, n_um_t = 0, n_um_d = 0;
+    assign_lists(d, s_cnt, Tc, D, n_pairs, d.max_dist, [&](int r) { return d.conf_idx[r]; }, [&](int c) { return c; }, d.matches, n_matches,
+                 d.um_t_a, n_um_t, d.um_d, n_um_d);
+    __syncthreads();
+    for (int q = threadIdx.x; q < Tu; q += 256) d.iou_cand[q] = d.unconf_idx[q];
+    const int c1 = compact_ordered(n_um_t, s_cnt, [&](int q) { return d.tab.tsu[d.um_t_a[q]] == 1; }, [&](int q, int r) { d.iou_cand[Tu + r] = d.um_t_a[q]; });
+    const int k1 = compact_ordered(n_um_t, s_cnt, [&](int q) { return d.tab.tsu[d.um_t_a[q]] != 1; }, [&](int q, int r) { d.um_t_keep[r] = d.um_t_a[q]; });
+    if (threadIdx.x == 0) {
+        d.meta[M_NM_A] = n_matches; d.meta[M_NUT_A] = n_um_t; d.meta[M_NKEEP] = k1;
+        d.meta[M_TB] = Tu + c1; d.meta[M_DB] = n_um_d;
+    }
+}
+
+// after the IOU-stage assignment: final lists, Tracker.update (tracker.py:129-176: Track.update / mark_missed /
+// _initiate_track, deleted tracks dropped) on the integer table, the lists the Kalman / gallery kernels consume,
+// and the output selection of DeepSort.update (deep_sort.py:67-71).
+__global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
+    __shared__ int s_cnt[4];
+    const int tid = threadIdx.x;
+    const int Tb = d.meta[M_TB], Db = d.meta[M_DB], k_keep = d.meta[M_NKEEP];
+    const int n_pairs = (Tb > 0 && Db > 0) ? d.meta[M_NB] : 0;
+    int n_matches = d.meta[M_NM_A], n_um_t_b = 0, n_um_d = 0;
+    int *um_t_b = d.um_t + k_keep;                                  // final unmatched tracks = [kept from stage A] + [stage B]
+    assign_lists(d, s_cnt, Tb, Db, n_pairs, d.max_iou, [&](int r) { return d.iou_cand[r]; }, [&](int c) { return d.um_d[c]; }, d.matches, n_matches,
+                 um_t_b, n_um_t_b, d.um_d2, n_um_d);
+    for (int q = tid; q < k_keep; q += 256) d.um_t[q] = d.um_t_keep[q];
+    __syncthreads();
+    const int M = n_matches, n_um_t = k_keep + n_um_t_b, Nn = n_um_d;
+    int T = d.meta[M_T];
+    // ---- Track.update (track.py:125-144) for every match
+    for (int k = tid; k < M; k += 256) {
+        const int t = d.matches[2 * k], det = d.matches[2 * k + 1];
+        int pos;
+        if (d.unbounded) { pos = d.tab.n_feat[t]; d.tab.n_feat[t] = pos + 1; }
+        else {
+            pos = d.tab.head[t];
+            d.tab.head[t] = (pos + 1) % d.budget;
+            d.tab.n_feat[t] = min(d.tab.n_feat[t] + 1, d.budget);
+        }
+        const int hits = ++d.tab.hits[t];
+        d.tab.tsu[t] = 0;
+        if (d.tab.state[t] == TENTATIVE && hits >= d.n_init) d.tab.state[t] = CONFIRMED;
+        d.tab.payload[t] = d.payload[det];
+        d.upd_slot[k] = d.tab.slot[t]; d.upd_det[k] = det; d.upd_pos[k] = pos;
+    }
+    // ---- Track.mark_missed (track.py:146-152)
+    for (int q = tid; q < n_um_t; q += 256) {
+        const int t = d.um_t[q];
+        if (d.tab.state[t] == TENTATIVE) d.tab.state[t] = DELETED;
+        else if (d.tab.tsu[t] > d.max_age) d.tab.state[t] = DELETED;
+    }
+    // ---- Tracker._initiate_track (tracker.py:49-54) for the unmatched detections, in list order
+    const int n_free = d.meta[M_NFREE], next_id = d.meta[M_NEXT_ID];
+    for (int k = tid; k < Nn; k += 256) {
+        const int t = T + k, slot = d.free_slots[n_free - 1 - k], det = d.um_d2[k];
+        d.tab.slot[t] = slot; d.tab.id[t] = next_id + k; d.tab.hits[t] = 1; d.tab.age[t] = 1; d.tab.tsu[t] = 0; d.tab.state[t] = TENTATIVE;
+        d.tab.n_feat[t] = 1; d.tab.head[t] = 1 % d.budget;
+        d.tab.payload[t] = d.payload[det];
+        d.new_slot[k] = slot;
+        // the feature / Kalman kernels take one combined list: entries [M, M + Nn) are the new tracks
+        d.upd_slot[M + k] = slot; d.upd_det[M + k] = det; d.upd_pos[M + k] = 0;
+    }
+    __syncthreads();
+    T += Nn;
+    // ---- drop deleted tracks (tracker.py:162), slots go back to the free list
+    const int alive = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] != DELETED; }, [&](int t, int r) {
+        d.tmp.slot[r] = d.tab.slot[t]; d.tmp.id[r] = d.tab.id[t]; d.tmp.hits[r] = d.tab.hits[t]; d.tmp.age[r] = d.tab.age[t]; d.tmp.tsu[r] = d.tab.tsu[t];
+        d.tmp.state[r] = d.tab.state[t]; d.tmp.n_feat[r] = d.tab.n_feat[t]; d.tmp.head[r] = d.tab.head[t]; d.tmp.payload[r] = d.tab.payload[t];
+    });
+    const int freed = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] == DELETED; },
+                                      [&](int t, int r) { d.free_slots[n_free - Nn + r] = d.tab.slot[t]; });
+    __syncthreads();
+    for (int t = tid; t < alive; t += 256) {
+        d.tab.slot[t] = d.tmp.slot[t]; d.tab.id[t] = d.tmp.id[t]; d.tab.hits[t] = d.tmp.hits[t]; d.tab.age[t] = d.tmp.age[t]; d.tab.tsu[t] = d.tmp.tsu[t];
+        d.tab.state[t] = d.tmp.state[t]; d.tab.n_feat[t] = d.tmp.n_feat[t]; d.tab.head[t] = d.tmp.head[t]; d.tab.payload[t] = d.tmp.payload[t];
+    }
+    __syncthreads();
+    // ---- output selection (deep_sort.py:67-71): confirmed and time_since_update <= 1, in list order
+    const int n_out = compact_ordered(alive, s_cnt, [&](int t) { return d.tab.state[t] == CONFIRMED && d.tab.tsu[t] <= 1; },
+                                      [&](int t, int r) { d.out_slot[r] = d.tab.slot[t]; d.out_id[r] = d.tab.id[t]; d.out_payload[r] = d.tab.payload[t]; });
+    // ---- debug lists for the parity tests
+    for (int k = tid; k < 2 * M; k += 256) d.res[d.res_matches + k] = d.matches[k];
+    for (int q = tid; q < n_um_t; q += 256) d.res[d.res_um_t + q] = d.um_t[q];
+    for (int q = tid; q < Nn; q += 256) d.res[d.res_um_d + q] = d.um_d2[q];
+    if (tid == 0) {
+        d.meta[M_T] = alive; d.meta[M_NEXT_ID] = next_id + Nn; d.meta[M_NFREE] = n_free - Nn + freed;
+        d.meta[M_NM] = M; d.meta[M_NUT] = n_um_t; d.meta[M_NUD] = Nn; d.meta[M_NOUT] = n_out;
+        for (int k = 0; k < M_COUNT; ++k) d.res[k] = d.meta[k];
+    }
+}
+
+// KalmanFilter.update for the matches (kalman_filter.py:161-204 via tracker.py:143-150), initiate for the new tracks
+// (:54-87), and the gallery rows of both (tracker.py:165-176 + nn_matching.py:152-155)
+__global__ void trk_kalman_kernel(TrkDev d) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = d.meta[M_NM], Nn = d.meta[M_NUD];
+    if (k >= M + Nn) return;
+    const int slot = d.upd_slot[k];
+    const float *b = d.tlwh + (size_t)d.upd_det[k] * 4;
+    float *m = d.mean + (size_t)slot * 8, *P = d.cov + (size_t)slot * 64;
+    if (k < M) {
+        float z[4];
+        to_xyah(b, z);
+        kf_update_body(m, P, z);
+    } else {
+        kf_initiate_body(m, P, b);
+    }
+}
+__global__ void trk_append_kernel(TrkDev d) {
+    const int k = blockIdx.x;
+    if (k >= d.meta[M_NM] + d.meta[M_NUD]) return;
+    float *dst = d.gallery + ((size_t)d.upd_slot[k] * d.budget + d.upd_pos[k]) * EMB;
+    const float *src = d.feats_n + (size_t)d.upd_det[k] * EMB;
+    for (int c = threadIdx.x; c < EMB; c += blockDim.x) dst[c] = src[c];
+}
+// deep_sort.py:73-87 on the selected tracks -> int32 rows in the result block
+__global__ void trk_output_kernel(TrkDev d) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= d.meta[M_NOUT]) return;
+    const float *m = d.mean + (size_t)d.out_slot[t] * 8;
+    float w = m[2] * m[3], h = m[3];
+    float x = m[0] - w / 2.f, y = m[1] - h / 2.f;
+    float x2 = w + x, y2 = h + y;
+    x = fmaxf(x, 0.f); y = fmaxf(y, 0.f);
+    int *o = d.res + d.res_out6 + t * 6;
+    o[0] = (int)x; o[1] = (int)y; o[2] = (int)x2; o[3] = (int)y2; o[4] = d.out_id[t]; o[5] = (int)d.out_payload[t];
+}
+
+// ============================================================================================ host
 class Tracker : public TrackerIface {
 public:
     // budget <= 0: nn_budget=None, every track keeps all its features (nn_matching.py:152-154) - the per-track row
-    // capacity `budget` then doubles whenever a gallery fills up; metric: cosine | euclidean (nn_matching.py:128-134)
+    // capacity `budget` then doubles whenever a gallery could fill up; metric: cosine | euclidean (nn_matching.py:128-134)
     Tracker(double max_dist, double max_iou, int max_age, int n_init, int budget, int metric = METRIC_COSINE)
         : max_dist(max_dist), max_iou(max_iou), max_age(max_age), n_init(n_init), budget(budget > 0 ? budget : 32), unbounded(budget <= 0),
           metric(metric) {
         if (metric != METRIC_COSINE && metric != METRIC_EUCLIDEAN) fail("Invalid metric; must be either 'euclidean' or 'cosine'");
         YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        feats_stage.st = feats_n.st = cost_dev.st = &stream;
+        det_lists.st = &stream;
+        meta.alloc(M_COUNT);
+        int init[M_COUNT] = {};
+        init[M_NEXT_ID] = 1;
+        YDS_HIP(hipMemcpy(meta.p, init, sizeof init, hipMemcpyHostToDevice));
         grow(256);
-        YDS_HIP(hipHostMalloc((void **)&ibuf_host, IBUF_INTS * sizeof(int), hipHostMallocMapped));
-        YDS_HIP(hipHostGetDevicePointer((void **)&ibuf_dev, ibuf_host, 0));
-        lsap_rows.alloc(LSAP_MAX);
-        lsap_cols.alloc(LSAP_MAX);
     }
     ~Tracker() override {
-        if (ibuf_host) (void)hipHostFree(ibuf_host);
+        if (res_host) (void)hipHostFree(res_host);
+        if (in_host) (void)hipHostFree(in_host);
         if (stream) (void)hipStreamDestroy(stream);
     }
-    int num_tracks() const override { return (int)tracks.size(); }
+    int num_tracks() const override { return T_host; }
 
+    static TrackTable table_at(int *base, int cap) {
+        TrackTable t;
+        t.slot = base; t.id = base + cap; t.hits = base + 2 * cap; t.age = base + 3 * cap; t.tsu = base + 4 * cap; t.state = base + 5 * cap;
+        t.n_feat = base + 6 * cap; t.head = base + 7 * cap; t.payload = reinterpret_cast<float *>(base + 8 * cap);
+        return t;
+    }
+
+    // capacity = number of slots = maximum number of live tracks.  Nothing may be in flight on the stream.
     void grow(int cap) {
+        YDS_HIP(hipStreamSynchronize(stream));
         DevBuf<float> m((size_t)cap * 8), c((size_t)cap * 64), g((size_t)cap * budget * EMB);
+        DevBuf<int> tab((size_t)cap * TAB_FIELDS), tmp((size_t)cap * TAB_FIELDS), fs(cap), lists((size_t)cap * 12);
         if (capacity) {
-            YDS_HIP(hipMemcpyAsync(m.p, mean.p, (size_t)capacity * 8 * 4, hipMemcpyDeviceToDevice, stream));
-            YDS_HIP(hipMemcpyAsync(c.p, cov.p, (size_t)capacity * 64 * 4, hipMemcpyDeviceToDevice, stream));
-            YDS_HIP(hipMemcpyAsync(g.p, gallery.p, (size_t)capacity * budget * EMB * 4, hipMemcpyDeviceToDevice, stream));
-            YDS_HIP(hipStreamSynchronize(stream));
+            YDS_HIP(hipMemcpy(m.p, mean.p, (size_t)capacity * 8 * 4, hipMemcpyDeviceToDevice));
+            YDS_HIP(hipMemcpy(c.p, cov.p, (size_t)capacity * 64 * 4, hipMemcpyDeviceToDevice));
+            YDS_HIP(hipMemcpy(g.p, gallery.p, (size_t)capacity * budget * EMB * 4, hipMemcpyDeviceToDevice));
+            for (int f = 0; f < TAB_FIELDS; ++f)
+                YDS_HIP(hipMemcpy(tab.p + (size_t)f * cap, table.p + (size_t)f * capacity, (size_t)capacity * 4, hipMemcpyDeviceToDevice));
         }
-        mean = std::move(m); cov = std::move(c); gallery = std::move(g);
-        for (int s = cap - 1; s >= capacity; --s) free_slots.push_back(s);
+        // free list: existing entries, then the new slots on top (popped first); the count lives in meta[M_NFREE]
+        int n_free = 0;
+        YDS_HIP(hipMemcpy(&n_free, meta.p + M_NFREE, 4, hipMemcpyDeviceToHost));
+        std::vector<int> fl(cap);
+        if (capacity && n_free) YDS_HIP(hipMemcpy(fl.data(), free_slots.p, (size_t)n_free * 4, hipMemcpyDeviceToHost));
+        for (int s = cap - 1; s >= capacity; --s) fl[n_free++] = s;
+        YDS_HIP(hipMemcpy(fs.p, fl.data(), (size_t)cap * 4, hipMemcpyHostToDevice));
+        YDS_HIP(hipMemcpy(meta.p + M_NFREE, &n_free, 4, hipMemcpyHostToDevice));
+        mean = std::move(m); cov = std::move(c); gallery = std::move(g); table = std::move(tab); table_tmp = std::move(tmp);
+        free_slots = std::move(fs); track_lists = std::move(lists);
         capacity = cap;
     }
     // nn_budget=None: double the per-track row capacity, keeping every slot's rows
     void grow_budget() {
+        YDS_HIP(hipStreamSynchronize(stream));
         const int nb = budget * 2;
         DevBuf<float> g((size_t)capacity * nb * EMB);
-        YDS_HIP(hipMemcpy2DAsync(g.p, (size_t)nb * EMB * 4, gallery.p, (size_t)budget * EMB * 4, (size_t)budget * EMB * 4, capacity,
-                                 hipMemcpyDeviceToDevice, stream));
-        YDS_HIP(hipStreamSynchronize(stream));
+        YDS_HIP(hipMemcpy2D(g.p, (size_t)nb * EMB * 4, gallery.p, (size_t)budget * EMB * 4, (size_t)budget * EMB * 4, capacity, hipMemcpyDeviceToDevice));
         gallery = std::move(g);
         budget = nb;
     }
-    // ring position for the next feature of a track (tracker.py:165-176 + nn_matching.py:152-155: last `budget` rows)
-    int next_row(Track &t) {
-        if (unbounded) {
-            if (t.n_feat == budget) grow_budget();
-            return t.n_feat++;
+
+    struct FrameIn { const float *tlwh; const float *feats; bool feats_on_device; const int *feat_rows; const float *payload; int D; };
+
+    // Enqueues one frame; T_ub = host-side upper bound of the live track count when it starts.  Returns the int offset of
+    // this frame's result block inside res_host / res_dev.
+    size_t enqueue(const FrameIn &f, int T_ub, size_t in_off, size_t res_off, size_t *res_len, int *out_cap) {
+        const int D = f.D, Dn = std::max(D, 1), Tn = std::max(T_ub, 1);
+        // ---- inputs: tlwh, payload (and feat_rows) were packed into in_host by the caller; one H2D per batch
+        TrkDev d;
+        d.tab = table_at(table.p, capacity); d.tmp = table_at(table_tmp.p, capacity);
+        d.meta = meta.p; d.free_slots = free_slots.p;
+        d.mean = mean.p; d.cov = cov.p; d.gallery = gallery.p;
+        feats_n.ensure_keep((size_t)Dn * EMB);
+        cost_dev.ensure_keep((size_t)(Tn + Dn) * Dn);
+        det_lists.ensure_keep((size_t)Dn * 8 + (size_t)(Tn + Dn) * 8);
+        d.feats_n = feats_n.p; d.cost = cost_dev.p;
+        d.tlwh = reinterpret_cast<const float *>(in_dev.p + in_off);
+        d.payload = d.tlwh + (size_t)D * 4;
+        const int *feat_rows_dev = f.feat_rows ? reinterpret_cast<const int *>(d.payload + D) : nullptr;
+        int *tl = track_lists.p;                                  // 12 lists of `capacity` ints
+        const int cap = capacity;
+        d.conf_idx = tl; d.unconf_idx = tl + cap; d.flag_r = tl + 2 * cap; d.um_t_a = tl + 3 * cap; d.um_t_keep = tl + 4 * cap; d.um_t = tl + 5 * cap;
+        d.iou_cand = tl + 6 * cap; d.out_slot = tl + 7 * cap; d.out_id = tl + 8 * cap; d.out_payload = reinterpret_cast<float *>(tl + 9 * cap);
+        d.rows = tl + 10 * cap; d.cols = tl + 11 * cap;
+        int *dl = det_lists.p;                                    // per-detection lists (D) and per-(track+det) lists
+        d.flag_c = dl; d.um_d = dl + Dn; d.um_d2 = dl + 2 * Dn; d.new_slot = dl + 3 * Dn; d.rej = dl + 4 * Dn;
+        int *pl = dl + 8 * (size_t)Dn;
+        const int P = Tn + Dn;
+        d.matches = pl; d.upd_slot = pl + 2 * P; d.upd_det = pl + 3 * P; d.upd_pos = pl + 4 * P;
+        d.budget = budget; d.unbounded = unbounded ? 1 : 0; d.n_init = n_init; d.max_age = max_age;
+        d.max_dist = (float)max_dist; d.max_iou = (float)max_iou;
+        // ---- result block layout: header | out6 rows | matches | unmatched tracks | unmatched detections
+        const int rows_cap = T_ub + D, mcap = std::min(T_ub + D, T_ub + D);
+        d.res_out6 = M_COUNT; d.res_matches = d.res_out6 + rows_cap * 6; d.res_um_t = d.res_matches + 2 * mcap; d.res_um_d = d.res_um_t + T_ub + D;
+        *res_len = (size_t)d.res_um_d + D + 1;
+        *out_cap = rows_cap;
+        d.res = res_dev.p + res_off;
+
+        // ---- kernels (sizes come from device memory; the grids use the host-side upper bounds)
+        const float *feats_dev = f.feats;
+        if (!f.feats_on_device && D) {
+            int n_rows = D;
+            if (f.feat_rows) for (int k = 0; k < D; ++k) n_rows = std::max(n_rows, f.feat_rows[k] + 1);
+            feats_stage.ensure_keep((size_t)n_rows * EMB);
+            YDS_HIP(hipMemcpyAsync(feats_stage.p, f.feats, (size_t)n_rows * EMB * 4, hipMemcpyHostToDevice, stream));
+            feats_dev = feats_stage.p;
         }
-        const int pos = t.head;
-        t.head = (t.head + 1) % budget;
-        t.n_feat = std::min(t.n_feat + 1, budget);
-        return pos;
+        if (D) hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, stream, feats_dev, feat_rows_dev, feats_n.p, D,
+                                  metric == METRIC_COSINE ? 1 : 0);     // x / ||x|| once per frame (nn_matching.py:50-52); euclidean: as is
+        hipLaunchKernelGGL(trk_begin_kernel, dim3(1), dim3(256), 0, stream, d, D);
+        if (T_ub) hipLaunchKernelGGL(trk_predict_kernel, dim3((T_ub + 63) / 64), dim3(64), 0, stream, d);
+        if (T_ub && D) {
+            hipLaunchKernelGGL(appearance_cost_kernel, dim3(T_ub, (D + 15) / 16), dim3(256), 0, stream, gallery.p, (const int *)nullptr,
+                               (const int *)nullptr, budget, feats_n.p, D, mean.p, cov.p, d.tlwh, (float)max_dist, (float)(max_dist + 1e-5), 1,
+                               metric == METRIC_EUCLIDEAN ? 1 : 0, cost_dev.p, d.conf_idx, d.tab.slot, d.tab.n_feat, meta.p + M_TC);
+            launch_lsap(cost_dev.p, T_ub, D, meta.p + M_TC, d.rows, d.cols, meta.p + M_NA, lsap_scratch, stream);
+        }
+        hipLaunchKernelGGL(trk_match_a_kernel, dim3(1), dim3(256), 0, stream, d);
+        if (T_ub && D) {
+            hipLaunchKernelGGL(iou_cost_kernel, dim3(((size_t)T_ub * D + 255) / 256), dim3(256), 0, stream, mean.p, (const int *)nullptr,
+                               (const int *)nullptr, 0, d.tlwh, d.um_d, 0, (float)max_iou, (float)(max_iou + 1e-5), cost_dev.p, meta.p + M_TB,
+                               d.iou_cand, d.tab.slot, d.tab.tsu);
+            launch_lsap(cost_dev.p, T_ub, D, meta.p + M_TB, d.rows, d.cols, meta.p + M_NB, lsap_scratch, stream);
+        }
+        hipLaunchKernelGGL(trk_match_b_kernel, dim3(1), dim3(256), 0, stream, d);
+        if (D) {
+            hipLaunchKernelGGL(trk_kalman_kernel, dim3((D + 63) / 64), dim3(64), 0, stream, d);
+            hipLaunchKernelGGL(trk_append_kernel, dim3(D), dim3(128), 0, stream, d);
+        }
+        if (rows_cap) hipLaunchKernelGGL(trk_output_kernel, dim3((rows_cap + 63) / 64), dim3(64), 0, stream, d);
+        YDS_HIP(hipGetLastError());
+        return res_off;
     }
 
-    // uploads an int vector into a scratch region and returns the device pointer
-    // Small index lists go through a pinned, device-mapped host ring: the kernels read them in place (a few hundred
-    // bytes over the host link) instead of paying one hipMemcpyAsync per list.  The ring is rewound once per step,
-    // after the step's final stream synchronisation.
-    const int *up(const std::vector<int> &v) {
-        if (v.empty()) return nullptr;
-        if (ibuf_used + v.size() > IBUF_INTS) fail("tracker: index scratch exhausted");
-        int *h = ibuf_host + ibuf_used;
-        memcpy(h, v.data(), v.size() * sizeof(int));
-        const int *d = ibuf_dev + ibuf_used;
-        ibuf_used += (v.size() + 3) / 4 * 4;
-        return d;
-    }
-
-    struct Assignment { std::vector<int> rows, cols; std::vector<float> cost; };
-
-    void solve(const float *cost_dev, int nr, int nc, Assignment &a) {
-        if (nr > LSAP_MAX || nc > LSAP_MAX) fail("tracker: assignment problem %dx%d exceeds %d", nr, nc, LSAP_MAX);
-        int n = std::min(nr, nc);
-        launch_lsap(cost_dev, nr, nc, lsap_rows.p, lsap_cols.p, stream);
-        a.rows.resize(n); a.cols.resize(n); a.cost.resize((size_t)nr * nc);
-        YDS_HIP(hipMemcpyAsync(a.rows.data(), lsap_rows.p, n * sizeof(int), hipMemcpyDeviceToHost, stream));
-        YDS_HIP(hipMemcpyAsync(a.cols.data(), lsap_cols.p, n * sizeof(int), hipMemcpyDeviceToHost, stream));
-        YDS_HIP(hipMemcpyAsync(a.cost.data(), cost_dev, a.cost.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    // One or several frames, in order, with ONE host synchronisation at the end.  counts[b] = rows of frame b.
+    void run(const FrameIn *frames, int n_frames, int32_t *const *out6, const int *caps, int *counts) {
+        // ---- capacity for the worst case: every detection of the batch starts a track, every frame adds a gallery row
+        int D_sum = 0;
+        for (int b = 0; b < n_frames; ++b) D_sum += frames[b].D;
+        if (T_host + D_sum > capacity) { int c = capacity; while (c < T_host + D_sum) c *= 2; grow(c); }
+        if (unbounded) while (max_rows_ub + n_frames + 1 > budget) grow_budget();
+        // ---- inputs of all frames in one pinned block, one upload
+        std::vector<size_t> in_off(n_frames);
+        size_t in_total = 0;
+        for (int b = 0; b < n_frames; ++b) { in_off[b] = in_total; in_total += (size_t)frames[b].D * 6 + 4; }
+        if (in_total > in_cap) {
+            if (in_host) (void)hipHostFree(in_host);
+            in_cap = in_total * 2;
+            YDS_HIP(hipHostMalloc((void **)&in_host, in_cap * sizeof(int)));
+            in_dev.alloc(in_cap);
+        }
+        for (int b = 0; b < n_frames; ++b) {
+            const FrameIn &f = frames[b];
+            float *dst = reinterpret_cast<float *>(in_host + in_off[b]);
+            if (f.D) {
+                memcpy(dst, f.tlwh, (size_t)f.D * 16);
+                memcpy(dst + (size_t)f.D * 4, f.payload, (size_t)f.D * 4);
+                if (f.feat_rows) memcpy(dst + (size_t)f.D * 5, f.feat_rows, (size_t)f.D * 4);
+            }
+        }
+        YDS_HIP(hipMemcpyAsync(in_dev.p, in_host, in_total * sizeof(int), hipMemcpyHostToDevice, stream));
+        // ---- result blocks
+        std::vector<size_t> res_off(n_frames), res_len(n_frames);
+        std::vector<int> out_cap(n_frames);
+        size_t res_total = 0;
+        {
+            int T_ub = T_host;
+            for (int b = 0; b < n_frames; ++b) { res_off[b] = res_total; res_total += (size_t)M_COUNT + (size_t)(T_ub + frames[b].D) * 10 + frames[b].D + 8; T_ub += frames[b].D; }
+        }
+        if (res_total > res_cap) {
+            YDS_HIP(hipStreamSynchronize(stream));
+            if (res_host) (void)hipHostFree(res_host);
+            res_cap = res_total * 2;
+            YDS_HIP(hipHostMalloc((void **)&res_host, res_cap * sizeof(int)));
+            res_dev.alloc(res_cap);
+        }
+        int T_ub = T_host;
+        for (int b = 0; b < n_frames; ++b) {
+            enqueue(frames[b], T_ub, in_off[b], res_off[b], &res_len[b], &out_cap[b]);
+            T_ub += frames[b].D;
+        }
+        YDS_HIP(hipMemcpyAsync(res_host, res_dev.p, res_total * sizeof(int), hipMemcpyDeviceToHost, stream));
         YDS_HIP(hipStreamSynchronize(stream));
-    }
-
-    // linear_assignment.py:58-72 list bookkeeping
-    void bookkeeping(const Assignment &a, int nc, float max_distance, const std::vector<int> &track_idx, const std::vector<int> &det_idx,
-                     std::vector<std::pair<int, int>> &matches, std::vector<int> &um_t, std::vector<int> &um_d) {
-        std::vector<char> col_used(det_idx.size(), 0), row_used(track_idx.size(), 0);
-        for (size_t k = 0; k < a.rows.size(); ++k) { row_used[a.rows[k]] = 1; col_used[a.cols[k]] = 1; }
-        for (size_t c = 0; c < det_idx.size(); ++c) if (!col_used[c]) um_d.push_back(det_idx[c]);
-        for (size_t r = 0; r < track_idx.size(); ++r) if (!row_used[r]) um_t.push_back(track_idx[r]);
-        for (size_t k = 0; k < a.rows.size(); ++k) {
-            int r = a.rows[k], c = a.cols[k];
-            if (a.cost[(size_t)r * nc + c] > max_distance) { um_t.push_back(track_idx[r]); um_d.push_back(det_idx[c]); }
-            else matches.emplace_back(track_idx[r], det_idx[c]);
+        for (int b = 0; b < n_frames; ++b) {
+            const int *r = res_host + res_off[b];
+            const int m = r[M_NOUT];
+            if (m > caps[b]) fail("tracker: %d output rows exceed the caller's capacity %d", m, caps[b]);
+            if (m) memcpy(out6[b], r + M_COUNT, (size_t)m * 6 * sizeof(int));
+            counts[b] = m;
         }
+        // ---- host-side mirror of the last frame (debug lists for the parity tests, live track count)
+        {
+            const int b = n_frames - 1, D = frames[b].D;
+            int T_before = T_host;
+            for (int k = 0; k < b; ++k) T_before += frames[k].D;         // upper bound used for that frame's layout
+            const int *r = res_host + res_off[b];
+            const int rows_cap = T_before + D;
+            const int *pm = r + M_COUNT + rows_cap * 6, *pt = pm + 2 * rows_cap, *pd = pt + rows_cap;
+            last_matches.assign(r[M_NM], {0, 0});
+            for (int k = 0; k < r[M_NM]; ++k) last_matches[k] = {pm[2 * k], pm[2 * k + 1]};
+            last_um_t.assign(pt, pt + r[M_NUT]);
+            std::sort(last_um_t.begin(), last_um_t.end());
+            last_um_d.assign(pd, pd + r[M_NUD]);
+            T_host = r[M_T];
+        }
+        max_rows_ub += n_frames;
     }
 
     int step(const float *tlwh_host, const float *feats, bool feats_on_device, const float *payload, int D, int32_t *out6, int cap) override {
@@ -571,151 +934,67 @@ public:
     // feat_rows (optional): detection d uses row feat_rows[d] of `feats` (tracker-side NMS keeps a subset in pick order)
     int step_sel(const float *tlwh_host, const float *feats, bool feats_on_device, const int *feat_rows, const float *payload, int D,
                  int32_t *out6, int cap) {
-        ibuf_used = 0;
-        const int T = (int)tracks.size();
-        tlwh_dev.ensure((size_t)std::max(D, 1) * 4);
-        if (D) YDS_HIP(hipMemcpyAsync(tlwh_dev.p, tlwh_host, (size_t)D * 16, hipMemcpyHostToDevice, stream));
-        const float *feats_dev = feats;
-        if (!feats_on_device && D) {
-            int n_rows = D;
-            if (feat_rows) for (int d = 0; d < D; ++d) n_rows = std::max(n_rows, feat_rows[d] + 1);
-            feats_stage.ensure((size_t)n_rows * EMB);
-            YDS_HIP(hipMemcpyAsync(feats_stage.p, feats, (size_t)n_rows * EMB * 4, hipMemcpyHostToDevice, stream));
-            feats_dev = feats_stage.p;
+        FrameIn f{tlwh_host, feats, feats_on_device, feat_rows, payload, D};
+        int count = 0;
+        run(&f, 1, &out6, &cap, &count);
+        return count;
+    }
+    // frames of one batch, in order, one synchronisation (the pipeline's association stage); skip[b]: tracker not called
+    void step_batch(int n, const float *tlwh_host, const int *first, const float *feats_dev, const float *payload, const char *skip, int32_t *out6,
+                    int cap, int32_t *counts) override {
+        std::vector<FrameIn> fr;
+        std::vector<int32_t *> outs;
+        std::vector<int> caps, cnt, which;
+        for (int b = 0; b < n; ++b) {
+            if (skip && skip[b]) { counts[b] = -1; continue; }
+            const int D = first[b + 1] - first[b];
+            fr.push_back(FrameIn{tlwh_host + (size_t)first[b] * 4, feats_dev + (size_t)first[b] * EMB, true, nullptr, payload + first[b], D});
+            outs.push_back(out6 + (size_t)b * cap * 6);
+            caps.push_back(cap);
+            which.push_back(b);
         }
-        if (D) {                                              // x / ||x|| once per frame (nn_matching.py:50-52); euclidean: as is
-            feats_n.ensure((size_t)D * EMB);
-            const int *rows_dev = nullptr;
-            if (feat_rows) { std::vector<int> r(feat_rows, feat_rows + D); rows_dev = up(r); }
-            hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, stream, feats_dev, rows_dev, feats_n.p, D,
-                               metric == METRIC_COSINE ? 1 : 0);
-        }
-        // ---- Tracker.predict (tracker.py:95-113)
-        if (T) {
-            std::vector<int> slots(T);
-            for (int i = 0; i < T; ++i) slots[i] = tracks[i].slot;
-            hipLaunchKernelGGL(kf_predict_kernel, dim3((T + 63) / 64), dim3(64), 0, stream, mean.p, cov.p, up(slots), T);
-            for (Track &t : tracks) { t.age++; t.tsu++; }
-        }
-        // ---- Tracker._match (tracker.py:56-93)
-        std::vector<int> confirmed, unconfirmed, all_dets(D);
-        for (int i = 0; i < T; ++i) (tracks[i].state == CONFIRMED ? confirmed : unconfirmed).push_back(i);
-        for (int d = 0; d < D; ++d) all_dets[d] = d;
-        std::vector<std::pair<int, int>> matches;
-        std::vector<int> um_t_a, um_d;
-        if (D == 0 || confirmed.empty()) {
-            um_t_a = confirmed;
-            um_d = all_dets;
-        } else {
-            const int Tc = (int)confirmed.size();
-            std::vector<int> slots(Tc), rows(Tc);
-            for (int r = 0; r < Tc; ++r) { slots[r] = tracks[confirmed[r]].slot; rows[r] = tracks[confirmed[r]].n_feat; }
-            cost_dev.ensure((size_t)Tc * D);
-            hipLaunchKernelGGL(appearance_cost_kernel, dim3(Tc, (D + 15) / 16), dim3(256), 0, stream, gallery.p, up(slots), up(rows), budget,
-                               feats_n.p, D, mean.p, cov.p, tlwh_dev.p, (float)max_dist, (float)(max_dist + 1e-5), 1, metric == METRIC_EUCLIDEAN ? 1 : 0, cost_dev.p);
-            Assignment a;
-            solve(cost_dev.p, Tc, D, a);
-            bookkeeping(a, D, (float)max_dist, confirmed, all_dets, matches, um_t_a, um_d);
-        }
-        std::vector<int> iou_cand = unconfirmed, um_t_keep;
-        for (int k : um_t_a) (tracks[k].tsu == 1 ? iou_cand : um_t_keep).push_back(k);
-        std::vector<int> um_t_b;
-        if (um_d.empty() || iou_cand.empty()) {
-            um_t_b = iou_cand;
-        } else {
-            const int Tb = (int)iou_cand.size(), Db = (int)um_d.size();
-            std::vector<int> slots(Tb), stale(Tb);
-            for (int r = 0; r < Tb; ++r) { slots[r] = tracks[iou_cand[r]].slot; stale[r] = tracks[iou_cand[r]].tsu > 1; }
-            cost_dev.ensure((size_t)Tb * Db);
-            hipLaunchKernelGGL(iou_cost_kernel, dim3((Tb * Db + 255) / 256), dim3(256), 0, stream, mean.p, up(slots), up(stale), Tb, tlwh_dev.p,
-                               up(um_d), Db, (float)max_iou, (float)(max_iou + 1e-5), cost_dev.p);
-            Assignment a;
-            solve(cost_dev.p, Tb, Db, a);
-            std::vector<int> um_d2;
-            bookkeeping(a, Db, (float)max_iou, iou_cand, um_d, matches, um_t_b, um_d2);
-            um_d = um_d2;
-        }
-        std::vector<int> unmatched_tracks = um_t_keep;
-        unmatched_tracks.insert(unmatched_tracks.end(), um_t_b.begin(), um_t_b.end());
-        last_matches = matches;
-        last_um_t = unmatched_tracks;
-        std::sort(last_um_t.begin(), last_um_t.end());
-        last_um_d = um_d;
-        // ---- Tracker.update (tracker.py:129-176)
-        const int M = (int)matches.size();
-        if (M) {
-            std::vector<int> slots(M), dets(M), pos(M);
-            for (int k = 0; k < M; ++k) {
-                Track &t = tracks[matches[k].first];
-                slots[k] = t.slot; dets[k] = matches[k].second; pos[k] = next_row(t);
-                t.hits++; t.tsu = 0;
-                if (t.state == TENTATIVE && t.hits >= n_init) t.state = CONFIRMED;
-                t.payload = payload[matches[k].second];
-            }
-            z_dev.ensure((size_t)M * 4);
-            const int *dslots = up(slots), *ddets = up(dets);
-            hipLaunchKernelGGL(tlwh_to_xyah_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, tlwh_dev.p, ddets, z_dev.p, M);
-            hipLaunchKernelGGL(kf_update_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, mean.p, cov.p, dslots, z_dev.p, M);
-            hipLaunchKernelGGL(feature_append_kernel, dim3(M), dim3(128), 0, stream, gallery.p, budget, dslots, up(pos), feats_n.p, ddets, M);
-        }
-        for (int k : unmatched_tracks) {                                   // Track.mark_missed track.py:146-152
-            Track &t = tracks[k];
-            if (t.state == TENTATIVE) t.state = DELETED;
-            else if (t.tsu > max_age) t.state = DELETED;
-        }
-        const int Nn = (int)um_d.size();
-        if (Nn) {                                                           // Tracker._initiate_track tracker.py:49-54
-            while ((int)free_slots.size() < Nn) grow(capacity * 2);
-            std::vector<int> slots(Nn), pos(Nn, 0);
-            for (int k = 0; k < Nn; ++k) {
-                Track t;
-                t.slot = free_slots.back(); free_slots.pop_back();
-                t.id = next_id++;
-                t.n_feat = 1; t.head = 1 % budget;
-                t.payload = payload[um_d[k]];
-                slots[k] = t.slot;
-                tracks.push_back(t);
-            }
-            const int *dslots = up(slots), *ddets = up(um_d);
-            hipLaunchKernelGGL(kf_initiate_kernel, dim3((Nn + 63) / 64), dim3(64), 0, stream, mean.p, cov.p, dslots, tlwh_dev.p, ddets, Nn);
-            hipLaunchKernelGGL(feature_append_kernel, dim3(Nn), dim3(128), 0, stream, gallery.p, budget, dslots, up(pos), feats_n.p, ddets, Nn);
-        }
-        std::vector<Track> alive;
-        for (const Track &t : tracks) {
-            if (t.state == DELETED) free_slots.push_back(t.slot);
-            else alive.push_back(t);
-        }
-        tracks.swap(alive);
-        // ---- output stage (deep_sort.py:63-88)
-        std::vector<int> slots, ids;
-        std::vector<float> pl;
-        for (const Track &t : tracks)
-            if (t.state == CONFIRMED && t.tsu <= 1) { slots.push_back(t.slot); ids.push_back(t.id); pl.push_back(t.payload); }
-        int m = (int)slots.size();
-        if (m > cap) fail("tracker: %d output rows exceed the caller's capacity %d", m, cap);
-        if (m) {
-            out_dev.ensure((size_t)m * 6);
-            pl_dev.upload(pl.data(), pl.size(), stream);
-            hipLaunchKernelGGL(output_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, mean.p, up(slots), up(ids), pl_dev.p, m, out_dev.p);
-            YDS_HIP(hipMemcpyAsync(out6, out_dev.p, (size_t)m * 6 * sizeof(int), hipMemcpyDeviceToHost, stream));
-        }
-        YDS_HIP(hipGetLastError());
-        YDS_HIP(hipStreamSynchronize(stream));
-        return m;
+        cnt.assign(fr.size(), 0);
+        if (!fr.empty()) run(fr.data(), (int)fr.size(), outs.data(), caps.data(), cnt.data());
+        for (size_t k = 0; k < which.size(); ++k) counts[which[k]] = cnt[k];
+    }
+
+    // host copy of the integer table (parity tests, DeepSort.tracker.tracks)
+    struct HostTable { std::vector<int> slot, id, hits, age, tsu, state, n_feat; };
+    HostTable read_table() {
+        HostTable h;
+        const int T = T_host;
+        auto get = [&](int field, std::vector<int> &v) {
+            v.resize(T);
+            if (T) YDS_HIP(hipMemcpy(v.data(), table.p + (size_t)field * capacity, (size_t)T * 4, hipMemcpyDeviceToHost));
+        };
+        get(0, h.slot); get(1, h.id); get(2, h.hits); get(3, h.age); get(4, h.tsu); get(5, h.state); get(6, h.n_feat);
+        return h;
     }
 
     double max_dist, max_iou;       // python floats in the reference; fp32 roundings are taken where torch/numpy take them
     int max_age, n_init, budget;
     bool unbounded = false;
     int metric = METRIC_COSINE;
-    int capacity = 0, next_id = 1;
-    std::vector<Track> tracks;
-    std::vector<int> free_slots;
-    DevBuf<float> mean, cov, gallery /* rows stored normalised */, tlwh_dev, feats_stage, feats_n, cost_dev, z_dev, pl_dev;
-    DevBuf<int> lsap_rows, lsap_cols, out_dev;
-    static constexpr size_t IBUF_INTS = 1 << 16;
-    int *ibuf_host = nullptr, *ibuf_dev = nullptr;
-    size_t ibuf_used = 0;
+    int capacity = 0;
+    int T_host = 0;                 // live tracks after the last synchronised frame
+    int max_rows_ub = 1;            // upper bound of any gallery's row count (unbounded mode: +1 per frame)
+    template <class T> struct GrowBuf : DevBuf<T> {
+        // ensure() that never shrinks and - unlike DevBuf::ensure - may only be called while nothing that uses the old buffer is
+        // in flight; growth is rare (sizes follow the largest frame seen), so it simply drains the stream first
+        hipStream_t *st = nullptr;
+        void ensure_keep(size_t count) {
+            if (count <= this->n) return;
+            if (st && *st) (void)hipStreamSynchronize(*st);
+            this->alloc(count + count / 2);
+        }
+    };
+    DevBuf<float> mean, cov, gallery /* cosine: rows stored normalised */;
+    DevBuf<int> table, table_tmp, free_slots, track_lists, meta, in_dev, res_dev;
+    GrowBuf<float> feats_stage, feats_n, cost_dev;
+    GrowBuf<int> det_lists;
+    DevBuf<char> lsap_scratch;
+    int *res_host = nullptr, *in_host = nullptr;
+    size_t res_cap = 0, in_cap = 0;
     std::vector<std::pair<int, int>> last_matches;
     std::vector<int> last_um_t, last_um_d;
     hipStream_t stream = nullptr;
@@ -789,17 +1068,20 @@ int yds_tracker_num_tracks(const yds_trk *t) { return t->t->num_tracks(); }
 int yds_tracker_get_state(yds_trk *t, int32_t *ids, int32_t *state, int32_t *tsu, int32_t *hits, float *mean8, float *cov64, int cap, int *T) {
     YDS_API_BEGIN
     yds::Tracker *k = impl(t);
-    int n = (int)k->tracks.size();
+    const int n = k->T_host;
     if (n > cap) yds::fail("tracker: %d tracks exceed cap %d", n, cap);
     *T = n;
+    const yds::Tracker::HostTable h = k->read_table();          // the table lives on the device; this is a debug / parity read-back
+    std::vector<float> m, c;
+    if (mean8 && n) { m.resize((size_t)k->capacity * 8); YDS_HIP(hipMemcpy(m.data(), k->mean.p, m.size() * 4, hipMemcpyDeviceToHost)); }
+    if (cov64 && n) { c.resize((size_t)k->capacity * 64); YDS_HIP(hipMemcpy(c.data(), k->cov.p, c.size() * 4, hipMemcpyDeviceToHost)); }
     for (int i = 0; i < n; ++i) {
-        const yds::Track &tr = k->tracks[i];
-        if (ids) ids[i] = tr.id;
-        if (state) state[i] = tr.state;
-        if (tsu) tsu[i] = tr.tsu;
-        if (hits) hits[i] = tr.hits;
-        if (mean8) YDS_HIP(hipMemcpy(mean8 + (size_t)i * 8, k->mean.p + (size_t)tr.slot * 8, 32, hipMemcpyDeviceToHost));
-        if (cov64) YDS_HIP(hipMemcpy(cov64 + (size_t)i * 64, k->cov.p + (size_t)tr.slot * 64, 256, hipMemcpyDeviceToHost));
+        if (ids) ids[i] = h.id[i];
+        if (state) state[i] = h.state[i];
+        if (tsu) tsu[i] = h.tsu[i];
+        if (hits) hits[i] = h.hits[i];
+        if (mean8) memcpy(mean8 + (size_t)i * 8, &m[(size_t)h.slot[i] * 8], 32);
+        if (cov64) memcpy(cov64 + (size_t)i * 64, &c[(size_t)h.slot[i] * 64], 256);
     }
     YDS_API_END
 }
@@ -817,14 +1099,14 @@ int yds_tracker_last_unmatched(yds_trk *t, int32_t *um_tracks, int cap_t, int *n
 int yds_lsap(const float *cost_host, int nr, int nc, int32_t *rows, int32_t *cols, int *n_out) {
     YDS_API_BEGIN
     using namespace yds;
-    if (nr > LSAP_MAX || nc > LSAP_MAX) fail("lsap: %dx%d exceeds %d", nr, nc, LSAP_MAX);
     int n = std::min(nr, nc);
     *n_out = n;
     if (n == 0) return 0;
     hipStream_t s = g_scratch.stream();
     DevBuf<float> c; c.upload(cost_host, (size_t)nr * nc, s);
     DevBuf<int> r(n), cc(n);
-    launch_lsap(c.p, nr, nc, r.p, cc.p, s);
+    DevBuf<char> scratch;
+    launch_lsap(c.p, nr, nc, nullptr, r.p, cc.p, nullptr, scratch, s);
     YDS_HIP(hipMemcpyAsync(rows, r.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
     YDS_HIP(hipMemcpyAsync(cols, cc.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
@@ -886,7 +1168,8 @@ int yds_iou_cost(const float *track_tlwh_host, int T, const float *det_tlwh_host
     m.upload(mean.data(), mean.size(), s); dt.upload(det_tlwh_host, (size_t)D * 4, s);
     auto v = iota(T); sl.upload(v.data(), T, s);
     auto w = iota(D); di.upload(w.data(), D, s);
-    hipLaunchKernelGGL(iou_cost_kernel, dim3((T * D + 255) / 256), dim3(256), 0, s, m.p, sl.p, (const int *)nullptr, T, dt.p, di.p, D, 0.f, 0.f, o.p);
+    hipLaunchKernelGGL(iou_cost_kernel, dim3((T * D + 255) / 256), dim3(256), 0, s, m.p, sl.p, (const int *)nullptr, T, dt.p, di.p, D, 0.f, 0.f, o.p, (const int *)nullptr, (const int *)nullptr,
+                       (const int *)nullptr, (const int *)nullptr);
     YDS_HIP(hipMemcpyAsync(out, o.p, (size_t)T * D * 4, hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
     YDS_API_END
@@ -913,7 +1196,8 @@ static int nn_min_cost(const float *gallery_host, const int32_t *seg_offsets_hos
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((G + 3) / 4), dim3(256), 0, s, gd.p, (const int *)nullptr, gn.p, G, euclid ? 0 : 1);
     hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, s, fd.p, (const int *)nullptr, fn.p, D, euclid ? 0 : 1);
     hipLaunchKernelGGL(appearance_cost_kernel, dim3(T, (D + 15) / 16), dim3(256), 0, s, gn.p, sl.p, nr.p, budget, fn.p, D,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, 0.f, 0, euclid, o.p);
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.f, 0.f, 0, euclid, o.p, (const int *)nullptr,
+                       (const int *)nullptr, (const int *)nullptr, (const int *)nullptr);
     YDS_HIP(hipMemcpyAsync(out, o.p, (size_t)T * D * 4, hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
     YDS_API_END

@@ -110,8 +110,15 @@ class Darknet:
         return self
 
     def half(self):
-        # img_detect.py:49-50; the engine computes in fp32 (north_star tolerance), flag kept for API parity
+        """img_detect.py:49-50 ``model.half()``: the convolutions switch to single-term fp16 operands (fp32 accumulation);
+        fp16-class accuracy, see tests/test_gpu_detector.py::test_half_mode for the measured tolerance."""
+        _lib.check(_lib.load().yds_darknet_set_half(self._h, 1))
         self._half = True
+        return self
+
+    def float(self):
+        _lib.check(_lib.load().yds_darknet_set_half(self._h, 0))
+        self._half = False
         return self
 
     def parameters(self):
