@@ -186,6 +186,8 @@ int yds_tracker_last_unmatched(yds_trk *, int32_t *um_tracks, int cap_t, int *n_
                                int32_t *um_dets, int cap_d, int *n_d);
 /* stand-alone association primitives (parity tests call these through the C ABI) */
 int yds_lsap(const float *cost_host, int nr, int nc, int32_t *rows, int32_t *cols, int *n_out);
+/* tuning aid: average duration of `iters` back-to-back LSAP launches on one cost matrix (HIP events) */
+int yds_lsap_bench(const float *cost_host, int nr, int nc, int iters, double *avg_us);
 int yds_kalman_predict(float *mean_host, float *cov_host, int T);
 int yds_kalman_update(float *mean_host, float *cov_host, const float *xyah_host, int M);
 int yds_kalman_gating(const float *mean_host, const float *cov_host, int T, const float *xyah_host, int D,

@@ -94,6 +94,7 @@ SIGNATURES = {
     "yds_tracker_get_state": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "yds_tracker_last_unmatched": (_I, [_P, _P, _I, _P, _P, _I, _P]),
     "yds_lsap": (_I, [_P, _I, _I, _P, _P, _P]),
+    "yds_lsap_bench": (_I, [_P, _I, _I, _I, _P]),
     "yds_kalman_predict": (_I, [_P, _P, _I]),
     "yds_kalman_update": (_I, [_P, _P, _P, _I]),
     "yds_kalman_gating": (_I, [_P, _P, _I, _P, _I, _P]),

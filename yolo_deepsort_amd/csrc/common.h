@@ -17,6 +17,7 @@ struct Error : std::runtime_error {
 [[noreturn]] void fail(const char *fmt, ...);
 int bound_device();     // device yds_init bound this process to, -1 before
 void bind_thread();     // selects that device for the calling host thread (hipSetDevice is per thread)
+hipStream_t make_stream(bool latency_role);   // non-blocking stream; optional CU partition between conv and association work
 
 #define YDS_HIP(expr)                                                                          \
     do {                                                                                       \

@@ -66,7 +66,7 @@ static std::vector<int> get_list(const CfgBlock &b, const char *k) {
 
 // ------------------------------------------------------------------------------------------ plan
 Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_max) : img_h(img_h), img_w(img_w), batch_max(batch_max) {
-    YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream = make_stream(false);
     auto blocks = parse_cfg(cfg_text);
     if (blocks.empty() || blocks[0].type != "net") fail("cfg: first section must be [net]");
     in_channels = geti(blocks[0], "channels");

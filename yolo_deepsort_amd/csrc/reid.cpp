@@ -24,7 +24,7 @@ constexpr int CROP_H = 128, CROP_W = 64, EMB = 512;
 
 ReidNet::ReidNet(int max_crops) : max_crops(max_crops) {
     if (max_crops < 1) fail("reid: max_crops must be positive");
-    YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    stream = make_stream(false);
 }
 ReidNet::~ReidNet() {
     if (stream) (void)hipStreamDestroy(stream);

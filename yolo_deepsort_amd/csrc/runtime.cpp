@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace yds {
@@ -32,6 +33,29 @@ void fail(const char *fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     throw Error(buf);
+}
+
+// Streams by role.  The association stage is a chain of small latency-bound kernels; the convolution kernels occupy every
+// CU completely (155 KB of LDS, all VGPRs), so on a shared chip each of those small kernels first waits for a conv
+// workgroup to retire.  YDS_RESERVE_CUS=n (opt-in, default 0) gives the latency role its own n compute units and keeps
+// the compute role off them (hipExtStreamCreateWithCUMask; complementary masks, so placement never affects results).
+hipStream_t make_stream(bool latency_role) {
+    hipStream_t st = nullptr;
+    static const int reserve = getenv("YDS_RESERVE_CUS") ? atoi(getenv("YDS_RESERVE_CUS")) : 0;
+    if (reserve > 0 && reserve < 128) {
+        hipDeviceProp_t prop;
+        YDS_HIP(hipGetDeviceProperties(&prop, bound_device() >= 0 ? bound_device() : 0));
+        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+        std::vector<uint32_t> mask(words, 0);
+        for (int cu = 0; cu < n_cu; ++cu) {
+            const bool mine = latency_role ? cu < reserve : cu >= reserve;
+            if (mine) mask[cu / 32] |= 1u << (cu % 32);
+        }
+        YDS_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+        return st;
+    }
+    YDS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    return st;
 }
 
 }  // namespace yds

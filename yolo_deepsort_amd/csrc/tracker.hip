@@ -297,11 +297,58 @@ __global__ void iou_cost_kernel(const float *mean, const int *slots, const int *
 // matrix too when it fits); beyond ~3000 rows/columns it moves to a global scratch buffer - no size limit.
 // dims_p (optional): device-side {nr, nc}.  row_out/col_out: min(nr,nc) pairs sorted by row, *n_out = that count.
 constexpr int LSAP_NT = 256, LSAP_NW = LSAP_NT / 64;
+
+// candidate of the column scan: shortest-path cost, tie-break key, column, owner row of that column
+struct LsapCand { double v; int key, col, own; };
+template <int CTRL> __device__ __forceinline__ LsapCand lsap_dpp(const LsapCand &c) {          // cross-lane move on the vector ALU (DPP)
+    LsapCand o;
+    union { double d; int i[2]; } u, w;
+    u.d = c.v;
+    w.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xF, 0xF, false);
+    w.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xF, 0xF, false);
+    o.v = w.d;
+    o.key = __builtin_amdgcn_update_dpp(c.key, c.key, CTRL, 0xF, 0xF, false);
+    o.col = __builtin_amdgcn_update_dpp(c.col, c.col, CTRL, 0xF, 0xF, false);
+    o.own = __builtin_amdgcn_update_dpp(c.own, c.own, CTRL, 0xF, 0xF, false);
+    return o;
+}
+__device__ __forceinline__ LsapCand lsap_lane(const LsapCand &c, int lane) {
+    LsapCand o;
+    union { double d; int i[2]; } u, w;
+    u.d = c.v;
+    w.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    w.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    o.v = w.d;
+    o.key = __builtin_amdgcn_readlane(c.key, lane);
+    o.col = __builtin_amdgcn_readlane(c.col, lane);
+    o.own = __builtin_amdgcn_readlane(c.own, lane);
+    return o;
+}
+__device__ __forceinline__ void lsap_take_min(LsapCand &a, const LsapCand &b) {
+    if (b.v < a.v || (b.v == a.v && b.key < a.key)) a = b;
+}
+// lexicographic (cost, key) minimum over the wavefront, result in every lane: four DPP butterflies inside each row of 16
+// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results through v_readlane.
+// (__shfl_xor lowers to ds_bpermute_b32 here: 18 dependent LDS-crossbar round trips per reduction.)
+__device__ __forceinline__ LsapCand lsap_wave_min(LsapCand c) {
+    lsap_take_min(c, lsap_dpp<0xB1>(c));
+    lsap_take_min(c, lsap_dpp<0x4E>(c));
+    lsap_take_min(c, lsap_dpp<0x141>(c));
+    lsap_take_min(c, lsap_dpp<0x140>(c));
+    LsapCand r = lsap_lane(c, 0);
+    lsap_take_min(r, lsap_lane(c, 16));
+    lsap_take_min(r, lsap_lane(c, 32));
+    lsap_take_min(r, lsap_lane(c, 48));
+    return r;
+}
 constexpr size_t LSAP_STATE_BYTES = 3 * sizeof(double) + 6 * sizeof(int);      // per row / column
 constexpr size_t LSAP_LDS_MAX = 150 * 1024;
 
+// GSTATE: solver state in the global scratch buffer (huge problems) instead of LDS - a compile-time choice, so that the LDS
+// version addresses its state with ds_read / ds_write (a pointer that may be either makes every access a flat_load)
+template <bool GSTATE, bool COST_LDS>
 __global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr0, int nc0, const int *dims_p, int *row_out, int *col_out,
-                                                       int *n_out, int cost_in_lds, char *state_global) {
+                                                       int *n_out, char *state_global) {
     if (dims_p) { nr0 = dims_p[0]; nc0 = dims_p[1]; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (nr0 <= 0 || nc0 <= 0) {                                  // linear_assignment.py:48-49 early-out
@@ -312,18 +359,24 @@ __global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr
     const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
     extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
     __shared__ double red_val[2][LSAP_NW];
-    __shared__ int red_key[2][LSAP_NW], red_col[2][LSAP_NW];
+    __shared__ int red_key[2][LSAP_NW], red_col[2][LSAP_NW], red_own[2][LSAP_NW];
     const int n = max(nr, nc);
-    char *base = state_global ? state_global : lsap_smem;
-    double *u = reinterpret_cast<double *>(base), *v = u + n, *spc = v + n;
-    int *path = reinterpret_cast<int *>(spc + n), *col4row = path + n, *row4col = col4row + n, *remaining = row4col + n, *SR = remaining + n,
-        *SC = SR + n;
-    float *cost_lds = reinterpret_cast<float *>(lsap_smem + (state_global ? 0 : (size_t)n * LSAP_STATE_BYTES));
-    if (cost_in_lds) {
+    double *u, *v, *spc;
+    int *path, *col4row, *row4col, *remaining, *SR, *SC;
+    auto carve = [&](char *base) {
+        u = reinterpret_cast<double *>(base); v = u + n; spc = v + n;
+        path = reinterpret_cast<int *>(spc + n); col4row = path + n; row4col = col4row + n; remaining = row4col + n; SR = remaining + n; SC = SR + n;
+    };
+    if (GSTATE) carve(state_global); else carve(lsap_smem);
+    float *cost_lds = reinterpret_cast<float *>(lsap_smem + (GSTATE ? 0 : (size_t)n * LSAP_STATE_BYTES));
+    if (COST_LDS) {
         for (int i = tid; i < nr0 * nc0; i += LSAP_NT) cost_lds[i] = cost[i];
     }
-    const float *cm = cost_in_lds ? cost_lds : cost;
-    auto C = [&](int i, int j) -> double { return (double)(transpose ? cm[(size_t)j * nc0 + i] : cm[(size_t)i * nc0 + j]); };
+    // (two typed accesses, not one pointer that may be LDS or global: that would be a flat_load in the inner loop)
+    auto C = [&](int i, int j) -> double {
+        const int at = transpose ? j * nc0 + i : i * nc0 + j;
+        return (double)(COST_LDS ? cost_lds[at] : cost[at]);
+    };
     for (int i = tid; i < nr; i += LSAP_NT) { u[i] = 0.0; col4row[i] = -1; }
     for (int j = tid; j < nc; j += LSAP_NT) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
     __syncthreads();
@@ -339,34 +392,29 @@ __global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr
             const double ui = u[i];
             // candidate = lexicographic minimum of (shortest path cost, key): among equal costs the LAST unassigned column in
             // `remaining` order, otherwise the FIRST column: unassigned -> 0x3fffffff - it, assigned -> 0x40000000 + it
-            double lmin = INFINITY;
-            int lkey = 0x7fffffff, lcol = -1;
+            LsapCand c{INFINITY, 0x7fffffff, -1, -1};
             for (int it = tid; it < num_remaining; it += LSAP_NT) {
                 const int j = remaining[it];
                 const double r = minVal + C(i, j) - ui - v[j];
                 double sv = spc[j];
                 if (r < sv) { path[j] = i; spc[j] = r; sv = r; }
-                const int key = row4col[j] == -1 ? 0x3fffffff - it : 0x40000000 + it;
-                if (sv < lmin || (sv == lmin && key < lkey)) { lmin = sv; lkey = key; lcol = j; }
+                const int own = row4col[j];
+                const int key = own == -1 ? 0x3fffffff - it : 0x40000000 + it;
+                if (sv < c.v || (sv == c.v && key < c.key)) { c.v = sv; c.key = key; c.col = j; c.own = own; }
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                const double os = __shfl_xor(lmin, o, 64);
-                const int ok = __shfl_xor(lkey, o, 64), oc = __shfl_xor(lcol, o, 64);
-                if (os < lmin || (os == lmin && ok < lkey)) { lmin = os; lkey = ok; lcol = oc; }
-            }
-            if (lane == 0) { red_val[parity][wave] = lmin; red_key[parity][wave] = lkey; red_col[parity][wave] = lcol; }
+            c = lsap_wave_min(c);
+            if (lane == 0) { red_val[parity][wave] = c.v; red_key[parity][wave] = c.key; red_col[parity][wave] = c.col; red_own[parity][wave] = c.own; }
             __syncthreads();
 #pragma unroll
             for (int w = 0; w < LSAP_NW; ++w) {
-                const double os = red_val[parity][w];
-                const int ok = red_key[parity][w];
-                if (os < lmin || (os == lmin && ok < lkey)) { lmin = os; lkey = ok; lcol = red_col[parity][w]; }
+                const LsapCand o{red_val[parity][w], red_key[parity][w], red_col[parity][w], red_own[parity][w]};
+                lsap_take_min(c, o);
             }
             parity ^= 1;
-            minVal = lmin;
-            const int index = lkey < 0x40000000 ? 0x3fffffff - lkey : lkey - 0x40000000;
-            const int j = lcol;
-            const int owner = row4col[j];
+            minVal = c.v;
+            const int index = c.key < 0x40000000 ? 0x3fffffff - c.key : c.key - 0x40000000;
+            const int j = c.col;
+            const int owner = c.own;
             if (owner == -1) sink = j; else i = owner;
             // swap-with-last removal, done by the thread that owns position `index` (the only future reader of it)
             if (tid == (index & (LSAP_NT - 1))) {
@@ -423,11 +471,14 @@ static void launch_lsap(const float *cost_dev, int nr_max, int nc_max, const int
     }
     static bool attr_set = false;
     if (!attr_set) {
-        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
         attr_set = true;
     }
-    hipLaunchKernelGGL(lsap_kernel, dim3(1), dim3(LSAP_NT), smem, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev, n_out_dev,
-                       cost_lds ? 1 : 0, state_lds ? (char *)nullptr : scratch.p);
+    auto kern = state_lds ? (cost_lds ? lsap_kernel<false, true> : lsap_kernel<false, false>) : lsap_kernel<true, false>;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(LSAP_NT), state_lds ? smem : 0, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev, n_out_dev,
+                       state_lds ? (char *)nullptr : scratch.p);
     YDS_HIP(hipGetLastError());
 }
 
@@ -724,7 +775,7 @@ public:
         : max_dist(max_dist), max_iou(max_iou), max_age(max_age), n_init(n_init), budget(budget > 0 ? budget : 32), unbounded(budget <= 0),
           metric(metric) {
         if (metric != METRIC_COSINE && metric != METRIC_EUCLIDEAN) fail("Invalid metric; must be either 'euclidean' or 'cosine'");
-        YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        stream = make_stream(true);
         feats_stage.st = feats_n.st = cost_dev.st = &stream;
         det_lists.st = &stream;
         meta.alloc(M_COUNT);
@@ -1110,6 +1161,27 @@ int yds_lsap(const float *cost_host, int nr, int nc, int32_t *rows, int32_t *col
     YDS_HIP(hipMemcpyAsync(rows, r.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
     YDS_HIP(hipMemcpyAsync(cols, cc.p, n * sizeof(int), hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
+    YDS_API_END
+}
+int yds_lsap_bench(const float *cost_host, int nr, int nc, int iters, double *avg_us) {
+    YDS_API_BEGIN
+    using namespace yds;
+    hipStream_t s = g_scratch.stream();
+    DevBuf<float> c; c.upload(cost_host, (size_t)nr * nc, s);
+    const int n = std::max(std::min(nr, nc), 1);
+    DevBuf<int> r(n), cc(n);
+    DevBuf<char> scratch;
+    hipEvent_t e0, e1;
+    YDS_HIP(hipEventCreate(&e0)); YDS_HIP(hipEventCreate(&e1));
+    launch_lsap(c.p, nr, nc, nullptr, r.p, cc.p, nullptr, scratch, s);
+    YDS_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) launch_lsap(c.p, nr, nc, nullptr, r.p, cc.p, nullptr, scratch, s);
+    YDS_HIP(hipEventRecord(e1, s));
+    YDS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    YDS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1e3 / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     YDS_API_END
 }
 int yds_kalman_predict(float *mean_host, float *cov_host, int T) {
