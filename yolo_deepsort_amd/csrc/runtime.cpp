@@ -35,25 +35,11 @@ void fail(const char *fmt, ...) {
     throw Error(buf);
 }
 
-// Streams by role.  The association stage is a chain of small latency-bound kernels; the convolution kernels occupy every
-// CU completely (155 KB of LDS, all VGPRs), so on a shared chip each of those small kernels first waits for a conv
-// workgroup to retire.  YDS_RESERVE_CUS=n (opt-in, default 0) gives the latency role its own n compute units and keeps
-// the compute role off them (hipExtStreamCreateWithCUMask; complementary masks, so placement never affects results).
-hipStream_t make_stream(bool latency_role) {
+// Non-blocking stream for a handle.  (A CU partition between the convolution streams and the association stream -
+// hipExtStreamCreateWithCUMask with complementary masks - was measured in round 2 and removed: masked streams ran the
+// association 1.6x (30 persons) to 5.6x (crowd) slower, see DESIGN.md.)
+hipStream_t make_stream(bool) {
     hipStream_t st = nullptr;
-    static const int reserve = getenv("YDS_RESERVE_CUS") ? atoi(getenv("YDS_RESERVE_CUS")) : 0;
-    if (reserve > 0 && reserve < 128) {
-        hipDeviceProp_t prop;
-        YDS_HIP(hipGetDeviceProperties(&prop, bound_device() >= 0 ? bound_device() : 0));
-        const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
-        std::vector<uint32_t> mask(words, 0);
-        for (int cu = 0; cu < n_cu; ++cu) {
-            const bool mine = latency_role ? cu < reserve : cu >= reserve;
-            if (mine) mask[cu / 32] |= 1u << (cu % 32);
-        }
-        YDS_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
-        return st;
-    }
     YDS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return st;
 }

@@ -297,52 +297,52 @@ __global__ void iou_cost_kernel(const float *mean, const int *slots, const int *
 // matrix too when it fits); beyond ~3000 rows/columns it moves to a global scratch buffer - no size limit.
 // dims_p (optional): device-side {nr, nc}.  row_out/col_out: min(nr,nc) pairs sorted by row, *n_out = that count.
 constexpr int LSAP_NT = 256, LSAP_NW = LSAP_NT / 64;
-
-// candidate of the column scan: shortest-path cost, tie-break key, column, owner row of that column
-struct LsapCand { double v; int key, col, own; };
-template <int CTRL> __device__ __forceinline__ LsapCand lsap_dpp(const LsapCand &c) {          // cross-lane move on the vector ALU (DPP)
-    LsapCand o;
-    union { double d; int i[2]; } u, w;
-    u.d = c.v;
-    w.i[0] = __builtin_amdgcn_update_dpp(u.i[0], u.i[0], CTRL, 0xF, 0xF, false);
-    w.i[1] = __builtin_amdgcn_update_dpp(u.i[1], u.i[1], CTRL, 0xF, 0xF, false);
-    o.v = w.d;
-    o.key = __builtin_amdgcn_update_dpp(c.key, c.key, CTRL, 0xF, 0xF, false);
-    o.col = __builtin_amdgcn_update_dpp(c.col, c.col, CTRL, 0xF, 0xF, false);
-    o.own = __builtin_amdgcn_update_dpp(c.own, c.own, CTRL, 0xF, 0xF, false);
-    return o;
-}
-__device__ __forceinline__ LsapCand lsap_lane(const LsapCand &c, int lane) {
-    LsapCand o;
-    union { double d; int i[2]; } u, w;
-    u.d = c.v;
-    w.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
-    w.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
-    o.v = w.d;
-    o.key = __builtin_amdgcn_readlane(c.key, lane);
-    o.col = __builtin_amdgcn_readlane(c.col, lane);
-    o.own = __builtin_amdgcn_readlane(c.own, lane);
-    return o;
-}
-__device__ __forceinline__ void lsap_take_min(LsapCand &a, const LsapCand &b) {
-    if (b.v < a.v || (b.v == a.v && b.key < a.key)) a = b;
-}
-// lexicographic (cost, key) minimum over the wavefront, result in every lane: four DPP butterflies inside each row of 16
-// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results through v_readlane.
-// (__shfl_xor lowers to ds_bpermute_b32 here: 18 dependent LDS-crossbar round trips per reduction.)
-__device__ __forceinline__ LsapCand lsap_wave_min(LsapCand c) {
-    lsap_take_min(c, lsap_dpp<0xB1>(c));
-    lsap_take_min(c, lsap_dpp<0x4E>(c));
-    lsap_take_min(c, lsap_dpp<0x141>(c));
-    lsap_take_min(c, lsap_dpp<0x140>(c));
-    LsapCand r = lsap_lane(c, 0);
-    lsap_take_min(r, lsap_lane(c, 16));
-    lsap_take_min(r, lsap_lane(c, 32));
-    lsap_take_min(r, lsap_lane(c, 48));
-    return r;
-}
+constexpr int LSAP_WAVE_COLS = 64;         // problems up to this many columns go to the single-wavefront kernel (below)
 constexpr size_t LSAP_STATE_BYTES = 3 * sizeof(double) + 6 * sizeof(int);      // per row / column
 constexpr size_t LSAP_LDS_MAX = 150 * 1024;
+
+// Cross-lane helpers of the LSAP kernels.  Everything is passed as scalars: with the candidate in a struct handled through
+// references the compiler kept it in scratch memory (a global-memory round trip per use inside a latency-bound loop).
+template <int CTRL> __device__ __forceinline__ int lsap_dpp_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+template <int CTRL> __device__ __forceinline__ double lsap_dpp_d(double x) {
+    union { double d; int i[2]; } u, w;
+    u.d = x;
+    w.i[0] = lsap_dpp_i<CTRL>(u.i[0]);
+    w.i[1] = lsap_dpp_i<CTRL>(u.i[1]);
+    return w.d;
+}
+__device__ __forceinline__ double lsap_readlane_d(double x, int lane) {
+    union { double d; int i[2]; } u, w;
+    u.d = x;
+    w.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    w.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return w.d;
+}
+// (v, key) <- lexicographic minimum with (ov, ok)
+#define LSAP_TAKE_MIN(v, key, ov, ok)                                      \
+    do {                                                                   \
+        const double _ov = (ov);                                           \
+        const int _ok = (ok);                                              \
+        const bool _t = _ov < (v) || (_ov == (v) && _ok < (key));          \
+        (v) = _t ? _ov : (v);                                              \
+        (key) = _t ? _ok : (key);                                          \
+    } while (0)
+// lexicographic (cost, key) minimum over the wavefront, result in every lane: four DPP butterflies inside each row of 16
+// lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the four row results through v_readlane.
+// (__shfl_xor lowers to ds_bpermute_b32 here: dependent LDS-crossbar round trips.)
+__device__ __forceinline__ void lsap_wave_min(double &v, int &key) {
+    LSAP_TAKE_MIN(v, key, lsap_dpp_d<0xB1>(v), lsap_dpp_i<0xB1>(key));
+    LSAP_TAKE_MIN(v, key, lsap_dpp_d<0x4E>(v), lsap_dpp_i<0x4E>(key));
+    LSAP_TAKE_MIN(v, key, lsap_dpp_d<0x141>(v), lsap_dpp_i<0x141>(key));
+    LSAP_TAKE_MIN(v, key, lsap_dpp_d<0x140>(v), lsap_dpp_i<0x140>(key));
+    double rv = lsap_readlane_d(v, 0);
+    int rk = __builtin_amdgcn_readlane(key, 0);
+    LSAP_TAKE_MIN(rv, rk, lsap_readlane_d(v, 16), __builtin_amdgcn_readlane(key, 16));
+    LSAP_TAKE_MIN(rv, rk, lsap_readlane_d(v, 32), __builtin_amdgcn_readlane(key, 32));
+    LSAP_TAKE_MIN(rv, rk, lsap_readlane_d(v, 48), __builtin_amdgcn_readlane(key, 48));
+    v = rv;
+    key = rk;
+}
 
 // GSTATE: solver state in the global scratch buffer (huge problems) instead of LDS - a compile-time choice, so that the LDS
 // version addresses its state with ds_read / ds_write (a pointer that may be either makes every access a flat_load)
@@ -355,11 +355,12 @@ __global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr
         if (tid == 0 && n_out) *n_out = 0;
         return;
     }
+    if (max(nr0, nc0) <= LSAP_WAVE_COLS) return;                 // solved by lsap_wave_kernel (launched in front of this one)
     const bool transpose = nc0 < nr0;
     const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
     extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
     __shared__ double red_val[2][LSAP_NW];
-    __shared__ int red_key[2][LSAP_NW], red_col[2][LSAP_NW], red_own[2][LSAP_NW];
+    __shared__ int red_key[2][LSAP_NW], red_col[2][LSAP_NW];
     const int n = max(nr, nc);
     double *u, *v, *spc;
     int *path, *col4row, *row4col, *remaining, *SR, *SC;
@@ -392,29 +393,36 @@ __global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr
             const double ui = u[i];
             // candidate = lexicographic minimum of (shortest path cost, key): among equal costs the LAST unassigned column in
             // `remaining` order, otherwise the FIRST column: unassigned -> 0x3fffffff - it, assigned -> 0x40000000 + it
-            LsapCand c{INFINITY, 0x7fffffff, -1, -1};
+            double cv = INFINITY;
+            int ckey = 0x7fffffff, cj = -1;
             for (int it = tid; it < num_remaining; it += LSAP_NT) {
                 const int j = remaining[it];
                 const double r = minVal + C(i, j) - ui - v[j];
                 double sv = spc[j];
                 if (r < sv) { path[j] = i; spc[j] = r; sv = r; }
-                const int own = row4col[j];
-                const int key = own == -1 ? 0x3fffffff - it : 0x40000000 + it;
-                if (sv < c.v || (sv == c.v && key < c.key)) { c.v = sv; c.key = key; c.col = j; c.own = own; }
+                const int key = row4col[j] == -1 ? 0x3fffffff - it : 0x40000000 + it;
+                const bool t = sv < cv || (sv == cv && key < ckey);
+                cv = t ? sv : cv; ckey = t ? key : ckey; cj = t ? j : cj;
             }
-            c = lsap_wave_min(c);
-            if (lane == 0) { red_val[parity][wave] = c.v; red_key[parity][wave] = c.key; red_col[parity][wave] = c.col; red_own[parity][wave] = c.own; }
+            const int my_key = ckey;
+            lsap_wave_min(cv, ckey);
+            if (my_key == ckey && ckey != 0x7fffffff) red_col[parity][wave] = cj;      // keys are unique: exactly one lane of the wave
+            if (lane == 0) { red_val[parity][wave] = cv; red_key[parity][wave] = ckey; }
             __syncthreads();
+            int win = 0;
+            cv = red_val[parity][0]; ckey = red_key[parity][0];
 #pragma unroll
-            for (int w = 0; w < LSAP_NW; ++w) {
-                const LsapCand o{red_val[parity][w], red_key[parity][w], red_col[parity][w], red_own[parity][w]};
-                lsap_take_min(c, o);
+            for (int w = 1; w < LSAP_NW; ++w) {
+                const double ov = red_val[parity][w];
+                const int ok = red_key[parity][w];
+                const bool t = ov < cv || (ov == cv && ok < ckey);
+                cv = t ? ov : cv; ckey = t ? ok : ckey; win = t ? w : win;
             }
+            const int j = red_col[parity][win];
             parity ^= 1;
-            minVal = c.v;
-            const int index = c.key < 0x40000000 ? 0x3fffffff - c.key : c.key - 0x40000000;
-            const int j = c.col;
-            const int owner = c.own;
+            minVal = cv;
+            const int index = ckey < 0x40000000 ? 0x3fffffff - ckey : ckey - 0x40000000;
+            const int owner = row4col[j];
             if (owner == -1) sink = j; else i = owner;
             // swap-with-last removal, done by the thread that owns position `index` (the only future reader of it)
             if (tid == (index & (LSAP_NT - 1))) {
@@ -457,9 +465,180 @@ __global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr
     if (tid == 0 && n_out) *n_out = nr;
 }
 
+// ---- single-wavefront form for problems with at most 256 columns (after the tall->wide transposition): every lane keeps
+// the scan state of up to four `remaining` positions (column, shortest-path cost, column dual, owner row) in REGISTERS, so a
+// Dijkstra step is one LDS cost read per position, the DPP reduction and a register hand-over for the swap-with-last
+// removal - no barrier and no LDS round trip on the critical path (the workgroup form above spends ~1 us per step).
+// Same arithmetic, same tie-break key, same result.
+constexpr int LSAP_WAVE_SLOTS = LSAP_WAVE_COLS / 64;
+constexpr size_t LSAP_WAVE_COST_MAX = 128 * 1024;               // cost matrix copied to LDS when it fits
+
+#ifndef YDS_LSAP_PROF
+#define YDS_LSAP_PROF 0
+#endif
+__device__ unsigned long long yds_lsap_prof[8];
+// SLOTS positions per lane (1: up to 64 columns, 4: up to 256).  A single wavefront issues one instruction every few cycles,
+// so the step is written for instruction count: only (cost, key) travel through the reduction - the key names the position,
+// whose lane then hands out column and owner - and inactive positions are masked with selects instead of branches.
+template <bool COST_LDS, int SLOTS>
+__device__ __forceinline__ void lsap_wave_solve(const float *cost, const float *cost_lds, int nr0, int nc0, char *smem, int *row_out, int *col_out) {
+    const int lane = threadIdx.x;
+    const bool transpose = nc0 < nr0;
+    const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
+    double *u = reinterpret_cast<double *>(smem), *v = u + LSAP_WAVE_COLS, *spc_rm = v + LSAP_WAVE_COLS;
+    int *path = reinterpret_cast<int *>(spc_rm + LSAP_WAVE_COLS), *col4row = path + LSAP_WAVE_COLS, *row4col = col4row + LSAP_WAVE_COLS,
+        *SR = row4col + LSAP_WAVE_COLS, *SC = SR + LSAP_WAVE_COLS;
+    const int sj = transpose ? nc0 : 1, si = transpose ? 1 : nc0;       // cost(i, j) at i * si + j * sj
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
+    __syncthreads();
+    for (int cur = 0; cur < nr; ++cur) {
+        int jj[SLOTS], ow[SLOTS], cofs[SLOTS];
+        double sp[SLOTS], vv[SLOTS];
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int it = lane + 64 * s, j = nc - 1 - it;          // `remaining` starts as nc-1 .. 0
+            const bool in = it < nc;
+            jj[s] = in ? j : 0; cofs[s] = jj[s] * sj; sp[s] = INFINITY;
+            vv[s] = v[jj[s]]; ow[s] = row4col[jj[s]];
+        }
+        for (int i = lane; i < nr; i += 64) SR[i] = 0;
+        for (int j = lane; j < nc; j += 64) SC[j] = 0;
+        __syncthreads();
+        double minVal = 0.0;
+        int num_remaining = nc, i = cur, sink = -1;
+        unsigned long long t_loop = YDS_LSAP_PROF ? __builtin_amdgcn_s_memtime() : 0, n_it = 0;
+        while (sink == -1) {
+            if (YDS_LSAP_PROF) ++n_it;
+            if (lane == 0) SR[i] = 1;
+            const double ui = u[i];
+            const int row_off = i * si;
+            double cv = INFINITY;
+            int ckey = 0x7fffffff;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int it = lane + 64 * s;
+                const bool active = it < num_remaining;
+                const int at = row_off + cofs[s];
+                const double cij = (double)(COST_LDS ? cost_lds[at] : cost[at]);
+                const double r = minVal + cij - ui - vv[s];            // scipy's order: minVal + cost - u[i] - v[j]
+                if (active && r < sp[s]) { path[jj[s]] = i; sp[s] = r; }
+                const int key = ow[s] == -1 ? 0x3fffffff - it : 0x40000000 + it;
+                LSAP_TAKE_MIN(cv, ckey, active ? sp[s] : (double)INFINITY, active ? key : 0x7fffffff);
+            }
+            lsap_wave_min(cv, ckey);
+            minVal = cv;
+            const int index = ckey < 0x40000000 ? 0x3fffffff - ckey : ckey - 0x40000000;
+            const int is = SLOTS == 1 ? 0 : index >> 6, il = index & 63;
+            // the position's lane hands out its column and owner
+            int j = 0, own = 0;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (s == is) { j = __builtin_amdgcn_readlane(jj[s], il); own = __builtin_amdgcn_readlane(ow[s], il); }
+            if (own == -1) sink = j; else i = own;
+            // swap-with-last removal: position `index` takes over the registers of position num_remaining - 1
+            const int last = __builtin_amdgcn_readfirstlane(num_remaining - 1);
+            const int ls = SLOTS == 1 ? 0 : last >> 6, ll = last & 63;
+            int t_j = 0, t_o = 0, t_c = 0;
+            union { double d; int w[2]; } t_sp, t_vv, a;
+            t_sp.d = 0.0; t_vv.d = 0.0;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (s == ls) {                                       // uniform
+                    t_j = __builtin_amdgcn_readlane(jj[s], ll);
+                    t_o = __builtin_amdgcn_readlane(ow[s], ll);
+                    t_c = __builtin_amdgcn_readlane(cofs[s], ll);
+                    a.d = sp[s]; t_sp.w[0] = __builtin_amdgcn_readlane(a.w[0], ll); t_sp.w[1] = __builtin_amdgcn_readlane(a.w[1], ll);
+                    a.d = vv[s]; t_vv.w[0] = __builtin_amdgcn_readlane(a.w[0], ll); t_vv.w[1] = __builtin_amdgcn_readlane(a.w[1], ll);
+                }
+            if (lane == il) { SC[j] = 1; spc_rm[j] = minVal; }       // the removed column keeps its shortest-path cost for the dual update
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const bool here = s == is && lane == il;
+                jj[s] = here ? t_j : jj[s]; ow[s] = here ? t_o : ow[s]; cofs[s] = here ? t_c : cofs[s];
+                sp[s] = here ? t_sp.d : sp[s]; vv[s] = here ? t_vv.d : vv[s];
+            }
+            --num_remaining;
+        }
+        if (YDS_LSAP_PROF && lane == 0) { yds_lsap_prof[0] += __builtin_amdgcn_s_memtime() - t_loop; yds_lsap_prof[1] += n_it; }
+        __syncthreads();
+        for (int r = lane; r < nr; r += 64) {
+            if (r == cur) u[r] += minVal;
+            else if (SR[r]) u[r] += minVal - spc_rm[col4row[r]];
+        }
+        for (int j = lane; j < nc; j += 64)
+            if (SC[j]) v[j] -= minVal - spc_rm[j];
+        __syncthreads();
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                int r = path[j];
+                row4col[j] = r;
+                int t = col4row[r]; col4row[r] = j; j = t;
+                if (r == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    if (transpose) {
+        if (lane == 0) {
+            int k = 0;
+            for (int r = 0; r < nc; ++r) {          // nc == original row count
+                int who = row4col[r];
+                if (who >= 0) { row_out[k] = r; col_out[k] = who; ++k; }
+            }
+        }
+    } else {
+        for (int r = lane; r < nr; r += 64) { row_out[r] = r; col_out[r] = col4row[r]; }
+    }
+}
+
+constexpr size_t LSAP_WAVE_STATE = (size_t)LSAP_WAVE_COLS * (3 * sizeof(double) + 5 * sizeof(int));
+// big = 0: this launch solves problems with <= 256 columns and leaves larger ones to the workgroup kernel (which is launched
+// with skip_small = 1 right behind it): the sizes are only known on the device, the host picks nothing.
+__global__ __launch_bounds__(64) void lsap_wave_kernel(const float *cost, int nr0, int nc0, const int *dims_p, int *row_out, int *col_out, int *n_out,
+                                                      int cost_lds_floats) {
+    if (dims_p) { nr0 = dims_p[0]; nc0 = dims_p[1]; }
+    extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
+    if (nr0 <= 0 || nc0 <= 0) {
+        if (threadIdx.x == 0 && n_out) *n_out = 0;
+        return;
+    }
+    if (max(nr0, nc0) > LSAP_WAVE_COLS) return;                 // the workgroup kernel's case
+    const unsigned long long t_k = YDS_LSAP_PROF ? __builtin_amdgcn_s_memtime() : 0, w_k = YDS_LSAP_PROF ? wall_clock64() : 0;
+    float *cost_lds = reinterpret_cast<float *>(lsap_smem + LSAP_WAVE_STATE);
+    const bool narrow = max(nr0, nc0) <= 64;                     // one position per lane
+    if (nr0 * nc0 <= cost_lds_floats) {
+        for (int i = threadIdx.x; i < nr0 * nc0; i += 64) cost_lds[i] = cost[i];
+        if (narrow) lsap_wave_solve<true, 1>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
+        else lsap_wave_solve<true, LSAP_WAVE_SLOTS>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
+    } else {
+        if (narrow) lsap_wave_solve<false, 1>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
+        else lsap_wave_solve<false, LSAP_WAVE_SLOTS>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
+    }
+    if (threadIdx.x == 0 && n_out) *n_out = min(nr0, nc0);
+    if (YDS_LSAP_PROF && threadIdx.x == 0) {
+        yds_lsap_prof[2] += __builtin_amdgcn_s_memtime() - t_k; yds_lsap_prof[3] += wall_clock64() - w_k; yds_lsap_prof[4] += 1;
+    }
+}
+
 // nr_max / nc_max: upper bounds known on the host (they size the LDS / scratch); the real sizes may come from dims_dev
 static void launch_lsap(const float *cost_dev, int nr_max, int nc_max, const int *dims_dev, int *rows_dev, int *cols_dev, int *n_out_dev,
                         DevBuf<char> &scratch, hipStream_t s) {
+    {
+        static bool wave_attr = false;
+        if (!wave_attr) {
+            YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(LSAP_WAVE_STATE + LSAP_WAVE_COST_MAX)));
+            wave_attr = true;
+        }
+        const size_t want = (size_t)std::min(nr_max, LSAP_WAVE_COLS) * std::min(nc_max, LSAP_WAVE_COLS) * sizeof(float);
+        const size_t cost_lds = std::min(want, LSAP_WAVE_COST_MAX);
+        hipLaunchKernelGGL(lsap_wave_kernel, dim3(1), dim3(64), LSAP_WAVE_STATE + cost_lds, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev,
+                           n_out_dev, (int)(cost_lds / sizeof(float)));
+        YDS_HIP(hipGetLastError());
+        if (std::max(nr_max, nc_max) <= LSAP_WAVE_COLS) return;
+    }
     const size_t n = (size_t)std::max(std::max(nr_max, nc_max), 1);
     const size_t state = n * LSAP_STATE_BYTES, cost_bytes = (size_t)nr_max * nc_max * sizeof(float);
     const bool state_lds = state <= LSAP_LDS_MAX;
@@ -1181,6 +1360,14 @@ int yds_lsap_bench(const float *cost_host, int nr, int nc, int iters, double *av
     float ms = 0;
     YDS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
+    if (YDS_LSAP_PROF) {
+        unsigned long long v[8];
+        YDS_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(yds_lsap_prof), sizeof v));
+        fprintf(stderr, "lsap prof: loop cycles/iter %.0f, iters/launch %.0f, kernel cycles %.0f, wall ticks(100MHz) %.0f -> %.2f GHz\n",
+                (double)v[0] / v[1], (double)v[1] / v[4], (double)v[2] / v[4], (double)v[3] / v[4], (double)v[2] / ((double)v[3] * 10.0));
+        unsigned long long z[8] = {};
+        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_lsap_prof), z, sizeof z));
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     YDS_API_END
 }
