@@ -92,7 +92,10 @@ struct FlatRows {
     int m0;
     __device__ __forceinline__ int operator()(int row) const { return m0 + row; }
 };
-template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, class RowMap = FlatRows>
+// ONE_PASS: the staging area holds the WHOLE tile (BM x (BN+4) floats instead of one row of waves): every wave stores its
+// accumulators at once and the workgroup sweeps all rows after a single barrier (2 barriers instead of 2 x WM, no waves
+// idling while one wave row is staged).  The caller sizes the LDS for it (conv_stage_bytes).
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, class RowMap = FlatRows, bool ONE_PASS = false>
 __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, RowMap rows, int n0, int tid) {
     constexpr int ROWS = BM / WM, LD = BN + 4, C4 = BN / 4;        // staged rows, padded row length, float4 per row
     constexpr int RSTEP = NT / C4;                                   // rows covered by one sweep of the NT threads
@@ -136,22 +139,23 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
     }
 #pragma unroll
     for (int pass = 0; pass < WM; ++pass) {
-        if (wm == pass) {
+        if (ONE_PASS ? pass == 0 : wm == pass) {
+            float *st = stage + (ONE_PASS ? wm * ROWS * LD : 0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        stage[(i * 32 + rsel + (e & 3) + 8 * (e >> 2)) * LD + wn * (BN / WN) + j * 32 + col] = acc[i][j][e];
+                        st[(i * 32 + rsel + (e & 3) + 8 * (e >> 2)) * LD + wn * (BN / WN) + j * 32 + col] = acc[i][j][e];
         }
-        __syncthreads();
+        if (!ONE_PASS || pass == 0) __syncthreads();
 #pragma unroll
         for (int k2 = 0; k2 < PER_PASS; ++k2) {
             const int r = rr + k2 * RSTEP;
             const int m = rows(pass * ROWS + r);
             const bool live = m >= 0 && m < p.M && n < p.Cout;   // no early exit: lane pairs trade halves below
-            float4 v = *reinterpret_cast<const float4 *>(stage + r * LD + c4 * 4);
+            float4 v = *reinterpret_cast<const float4 *>(stage + (ONE_PASS ? pass * ROWS * LD : 0) + r * LD + c4 * 4);
             float rs[4] = {0.f, 0.f, 0.f, 0.f};
             if (RES != RES_NONE && live) {
                 const float4 t = rraw[RES != RES_NONE ? pass * PER_PASS + k2 : 0];
@@ -191,13 +195,14 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
                 else { yp[n] = o[0]; if (n + 1 < p.Cout) yp[n + 1] = o[1]; if (n + 2 < p.Cout) yp[n + 2] = o[2]; }
             }
         }
-        if (pass + 1 < WM) __syncthreads();
+        if (!ONE_PASS && pass + 1 < WM) __syncthreads();
     }
 }
+constexpr size_t conv_stage_bytes(int BM, int BN) { return (size_t)BM * (BN + 4) * sizeof(float); }
 
-template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256>
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, bool ONE_PASS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
-    conv_epilogue_rows<BM, BN, WM, WN, ACT, RES, TM, TN, NT, FlatRows>(p, acc, stage, FlatRows{m0}, n0, tid);
+    conv_epilogue_rows<BM, BN, WM, WN, ACT, RES, TM, TN, NT, FlatRows, ONE_PASS>(p, acc, stage, FlatRows{m0}, n0, tid);
 }
 
 ConvKernelArgs make_conv_args(const ConvArgs &a);

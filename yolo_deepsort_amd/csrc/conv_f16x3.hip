@@ -230,14 +230,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
-    static_assert((BM / WM) * (BN + 4) * 4 <= 2 * (BM + BN) * ROWB, "epilogue staging must fit the main-loop LDS");
+    static_assert(BM * (BN + 4) * 4 <= 2 * (BM + BN) * ROWB, "whole-tile epilogue staging must fit the main-loop LDS");
     if (YDS_F16_ABL == 5) {                                   // ablation 5: K loop only
         float t = 0.f;
         for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int e = 0; e < 16; ++e) t += acc1[i][j][e];
         if (t == 123.456f) p.y[0] = t;
         return;
     }
-    conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc1, reinterpret_cast<float *>(smem16), m0, n0, tid);
+    conv_epilogue<BM, BN, WM, WN, ACT, RES, BM / WM / 32, BN / WN / 32, 256, true>(p, acc1, reinterpret_cast<float *>(smem16), m0, n0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -254,8 +254,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
 
 constexpr int ZERO_PAGE_BYTES = 64 * 1024;                      // >= Cin * 4 + 128 for every layer (checked at launch)
 
+constexpr size_t dma_smem_bytes(int BM, int BN, int NS) {
+    return (size_t)NS * (BM + BN) * 128 > conv_stage_bytes(BM, BN) ? (size_t)NS * (BM + BN) * 128 : conv_stage_bytes(BM, BN);
+}
 template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS>
-__global__ __launch_bounds__(WM * WN * 64, (NS * (BM + BN) * 128 <= 80 * 1024 && WM * WN == 4) ? 2 : 1)
+__global__ __launch_bounds__(WM * WN * 64, (dma_smem_bytes(BM, BN, NS) <= 80 * 1024 && WM * WN == 4) ? 2 : 1)
 void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -449,8 +452,8 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
-    static_assert((BM / WM) * (BN + 4) * 4 <= NS * STAGE, "epilogue staging must fit the ring");
-    conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT>(p, acc1, reinterpret_cast<float *>(ring), m0, n0, tid);
+    // whole-tile staging: the launcher sizes the LDS as max(ring, BM x (BN+4) floats)
+    conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT, true>(p, acc1, reinterpret_cast<float *>(ring), m0, n0, tid);
 }
 
 static const char *zero_page_dev() {
@@ -463,7 +466,7 @@ static const char *zero_page_dev() {
 }
 
 template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS> static void launch_inst_dma(ConvKernelArgs k, hipStream_t s) {
-    constexpr size_t smem = (size_t)NS * (BM + BN) * 128;
+    constexpr size_t smem = dma_smem_bytes(BM, BN, NS);
     static bool attr_set = false;
     auto kern = conv_igemm_f16x3_dma<BM, BN, WM, WN, NS, ACT, RES, TERMS>;
     if (!attr_set) {

@@ -244,14 +244,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
-    conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);
+    conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT, true>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);   // whole-tile staging
 }
 
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
 
 template <int BN, int WM, int WN, int ACT, int RES, int TERMS = 3> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
     const int wrows = window_rows(k.W), nbuf = k.Cin == 32 ? 1 : 2;
-    const size_t smem = (size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW;
+    // (the epilogue stages the whole 256 x BN tile in the same LDS: narrow images need more than their windows + ring)
+    const size_t smem = std::max((size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW, conv_stage_bytes(BM, BN));
     static size_t attr_set = 0;
     auto kern = conv3x3_f16x3_win<BN, WM, WN, ACT, RES, TERMS>;
     if (smem > attr_set) {
@@ -271,7 +272,7 @@ bool conv_win_applicable(const ConvKernelArgs &k) {
     // several channel groups: the next group's window is fetched by at most APW instructions per wave while this one is
     // consumed (two buffers); a single group needs one buffer only, which admits much wider images
     if (nbuf == 2 && wrows > MAX_WROWS) return false;
-    // (the epilogue stages (BM/WM) x (BN+4) floats in the same LDS)
+    // (the epilogue stages BM x (BN+4) floats in the same LDS: 135 KB at BN = 128)
     return (size_t)nbuf * wrows * ROW + (size_t)NSB * 128 * ROW + ROW <= 160 * 1024 && (size_t)k.M * (k.ldx / 4) < (1ull << 32);
 }
 
