@@ -112,90 +112,105 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
         if (n + 1 < p.Cout) bias4.y = p.bias[n + 1];
         if (n + 2 < p.Cout) bias4.z = p.bias[n + 2];
     }
-    // The residual rows of ALL passes are fetched up front: the loads are in flight while the first wave row goes through
-    // LDS, instead of paying one exposed global-load latency per pass (each pass sits between two barriers).
+    // The tensor formats are uniform run-time flags; the sweep is instantiated per (output H16?, residual H16?) and entered
+    // through ONE uniform branch, so its loops carry no format tests (the generic form spent a third of its instructions on
+    // exec-mask bookkeeping and re-tested the formats in every iteration).
     constexpr int PER_PASS = ROWS / RSTEP, NRES = RES != RES_NONE ? WM * PER_PASS : 1;
-    float4 rraw[NRES];
-    if (RES != RES_NONE) {
+    auto sweep = [&](auto yh_c, auto rh_c) {
+        constexpr bool YH = decltype(yh_c)::value, RH = decltype(rh_c)::value;
+        // The residual rows of ALL passes are fetched up front: the loads are in flight while the tile goes through LDS,
+        // instead of paying one exposed global-load latency per pass.
+        float4 rraw[NRES];
+        if (RES != RES_NONE) {
 #pragma unroll
-        for (int q = 0; q < NRES; ++q) {
-            const int m = rows((q / PER_PASS) * ROWS + rr + (q % PER_PASS) * RSTEP);
-            rraw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m >= 0 && m < p.M && n < p.Cout) {
-                const float *rp = p.res + (size_t)m * p.ldr;
-                if (p.fmt_r == FMT_H16) {                                      // H16 tensors have Cout % 32 == 0: [hi 8 B | lo 8 B]
-                    const char *g = reinterpret_cast<const char *>(rp + (n & ~31)) + (n & 31) * 2;
-                    const float2 hi = *reinterpret_cast<const float2 *>(g), lo = *reinterpret_cast<const float2 *>(g + 64);
-                    rraw[q] = make_float4(hi.x, hi.y, lo.x, lo.y);
-                } else if (n_vec) {
-                    rraw[q] = *reinterpret_cast<const float4 *>(rp + n);
-                } else {
-                    rraw[q].x = rp[n];
-                    if (n + 1 < p.Cout) rraw[q].y = rp[n + 1];
-                    if (n + 2 < p.Cout) rraw[q].z = rp[n + 2];
+            for (int q = 0; q < NRES; ++q) {
+                const int m = rows((q / PER_PASS) * ROWS + rr + (q % PER_PASS) * RSTEP);
+                rraw[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m >= 0 && m < p.M && n < p.Cout) {
+                    const float *rp = p.res + (size_t)m * p.ldr;
+                    if (RH) {                                                      // H16 tensors have Cout % 32 == 0: [hi 8 B | lo 8 B]
+                        const char *g = reinterpret_cast<const char *>(rp + (n & ~31)) + (n & 31) * 2;
+                        const float2 hi = *reinterpret_cast<const float2 *>(g), lo = *reinterpret_cast<const float2 *>(g + 64);
+                        rraw[q] = make_float4(hi.x, hi.y, lo.x, lo.y);
+                    } else if (n_vec) {
+                        rraw[q] = *reinterpret_cast<const float4 *>(rp + n);
+                    } else {
+                        rraw[q].x = rp[n];
+                        if (n + 1 < p.Cout) rraw[q].y = rp[n + 1];
+                        if (n + 2 < p.Cout) rraw[q].z = rp[n + 2];
+                    }
                 }
             }
         }
-    }
 #pragma unroll
-    for (int pass = 0; pass < WM; ++pass) {
-        if (ONE_PASS ? pass == 0 : wm == pass) {
-            float *st = stage + (ONE_PASS ? wm * ROWS * LD : 0);
+        for (int pass = 0; pass < WM; ++pass) {
+            if (ONE_PASS ? pass == 0 : wm == pass) {
+                float *st = stage + (ONE_PASS ? wm * ROWS * LD : 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        st[(i * 32 + rsel + (e & 3) + 8 * (e >> 2)) * LD + wn * (BN / WN) + j * 32 + col] = acc[i][j][e];
+                        for (int e = 0; e < 16; ++e)
+                            st[(i * 32 + rsel + (e & 3) + 8 * (e >> 2)) * LD + wn * (BN / WN) + j * 32 + col] = acc[i][j][e];
+            }
+            if (!ONE_PASS || pass == 0) __syncthreads();
+#pragma unroll
+            for (int k2 = 0; k2 < PER_PASS; ++k2) {
+                const int r = rr + k2 * RSTEP;
+                const int m = rows(pass * ROWS + r);
+                const bool live = m >= 0 && m < p.M && n < p.Cout;   // no early exit: lane pairs trade halves below
+                float4 v = *reinterpret_cast<const float4 *>(stage + (ONE_PASS ? pass * ROWS * LD : 0) + r * LD + c4 * 4);
+                float rs[4] = {0.f, 0.f, 0.f, 0.f};
+                if (RES != RES_NONE) {
+                    const float4 t = rraw[RES != RES_NONE ? pass * PER_PASS + k2 : 0];     // zeros where the row is not live
+                    if (RH) {
+                        union { float2 f; h16x4 h; } uh, ul;
+                        uh.f = make_float2(t.x, t.y);
+                        ul.f = make_float2(t.z, t.w);
+                        h16_decode4(uh.h, ul.h, rs);
+                    } else { rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
+                }
+                float o[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (RES == RES_BEFORE_ACT) o[k] += rs[k];
+                    o[k] = apply_act<ACT>(o[k]);
+                    if (RES == RES_AFTER_ACT) o[k] += rs[k];
+                }
+                float *yp = p.y + (size_t)m * p.ldy;
+                if (YH) {
+                    // neighbouring lanes hold neighbouring channel quads of the same pixel: they trade halves so that each lane
+                    // issues ONE 16-byte store (even lane: 8 hi halves, odd lane: 8 lo halves) instead of two 8-byte ones.
+                    // The trade is a DPP quad permute [1,0,3,2] on the vector ALU (__shfl_xor goes through the LDS crossbar).
+                    h16x4 hi, lo;
+                    h16_encode4(o, hi, lo);
+                    const bool odd = c4 & 1;
+                    union { h16x4 h; int i[2]; } send, recv;
+                    send.h = odd ? hi : lo;
+                    recv.i[0] = __builtin_amdgcn_update_dpp(send.i[0], send.i[0], 0xB1, 0xF, 0xF, false);
+                    recv.i[1] = __builtin_amdgcn_update_dpp(send.i[1], send.i[1], 0xB1, 0xF, 0xF, false);
+                    union { h16x4 h[2]; float4 f; } out;
+                    out.h[0] = odd ? recv.h : hi;
+                    out.h[1] = odd ? lo : recv.h;
+                    const int nq = n & ~7;                                          // first channel of the lane pair
+                    char *g = reinterpret_cast<char *>(yp + (nq & ~31)) + (nq & 31) * 2 + (odd ? 64 : 0);
+                    if (live) *reinterpret_cast<float4 *>(g) = out.f;
+                } else if (live) {
+                    if (n_vec) *reinterpret_cast<float4 *>(yp + n) = make_float4(o[0], o[1], o[2], o[3]);
+                    else { yp[n] = o[0]; if (n + 1 < p.Cout) yp[n + 1] = o[1]; if (n + 2 < p.Cout) yp[n + 2] = o[2]; }
+                }
+            }
+            if (!ONE_PASS && pass + 1 < WM) __syncthreads();
         }
-        if (!ONE_PASS || pass == 0) __syncthreads();
-#pragma unroll
-        for (int k2 = 0; k2 < PER_PASS; ++k2) {
-            const int r = rr + k2 * RSTEP;
-            const int m = rows(pass * ROWS + r);
-            const bool live = m >= 0 && m < p.M && n < p.Cout;   // no early exit: lane pairs trade halves below
-            float4 v = *reinterpret_cast<const float4 *>(stage + (ONE_PASS ? pass * ROWS * LD : 0) + r * LD + c4 * 4);
-            float rs[4] = {0.f, 0.f, 0.f, 0.f};
-            if (RES != RES_NONE && live) {
-                const float4 t = rraw[RES != RES_NONE ? pass * PER_PASS + k2 : 0];
-                if (p.fmt_r == FMT_H16) {
-                    union { float2 f; h16x4 h; } uh, ul;
-                    uh.f = make_float2(t.x, t.y);
-                    ul.f = make_float2(t.z, t.w);
-                    h16_decode4(uh.h, ul.h, rs);
-                } else { rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
-            }
-            float o[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (RES == RES_BEFORE_ACT) o[k] += rs[k];
-                o[k] = apply_act<ACT>(o[k]);
-                if (RES == RES_AFTER_ACT) o[k] += rs[k];
-            }
-            float *yp = p.y + (size_t)m * p.ldy;
-            if (p.fmt_y == FMT_H16) {
-                // neighbouring lanes hold neighbouring channel quads of the same pixel: they trade halves so that each lane
-                // issues ONE 16-byte store (even lane: 8 hi halves, odd lane: 8 lo halves) instead of two 8-byte ones
-                h16x4 hi, lo;
-                h16_encode4(o, hi, lo);
-                const bool odd = c4 & 1;
-                union { h16x4 h; int i[2]; } send, recv;
-                send.h = odd ? hi : lo;
-                recv.i[0] = __shfl_xor(send.i[0], 1);
-                recv.i[1] = __shfl_xor(send.i[1], 1);
-                union { h16x4 h[2]; float4 f; } out;
-                out.h[0] = odd ? recv.h : hi;
-                out.h[1] = odd ? lo : recv.h;
-                const int nq = n & ~7;                                          // first channel of the lane pair
-                char *g = reinterpret_cast<char *>(yp + (nq & ~31)) + (nq & 31) * 2 + (odd ? 64 : 0);
-                if (live) *reinterpret_cast<float4 *>(g) = out.f;
-            } else if (live) {
-                if (n_vec) *reinterpret_cast<float4 *>(yp + n) = make_float4(o[0], o[1], o[2], o[3]);
-                else { yp[n] = o[0]; if (n + 1 < p.Cout) yp[n + 1] = o[1]; if (n + 2 < p.Cout) yp[n + 2] = o[2]; }
-            }
-        }
-        if (!ONE_PASS && pass + 1 < WM) __syncthreads();
+    };
+    const bool yh = p.fmt_y == FMT_H16, rh = RES != RES_NONE && p.fmt_r == FMT_H16;
+    if (yh) {
+        if (rh) sweep(std::true_type{}, std::true_type{});
+        else sweep(std::true_type{}, std::false_type{});
+    } else {
+        if (rh) sweep(std::false_type{}, std::true_type{});
+        else sweep(std::false_type{}, std::false_type{});
     }
 }
 constexpr size_t conv_stage_bytes(int BM, int BN) { return (size_t)BM * (BN + 4) * sizeof(float); }
