@@ -202,16 +202,16 @@ struct YoloParams {
 
 __global__ void yolo_decode_kernel(const float *head, float *out, int N, int H, int W, int ld, int A, int attrs, int total_boxes,
                                    int box_off, YoloParams yp) {
-    const int HW = H * W;
-    const size_t per_img = (size_t)A * HW * attrs;
-    const size_t total = per_img * N;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        int t = idx % attrs;
-        size_t b = idx / attrs;
-        int box = b % ((size_t)A * HW);
-        int n = b / ((size_t)A * HW);
-        int a = box / HW, cell = box - a * HW;
-        int gy = cell / W, gx = cell - gy * W;
+    // one image per blockIdx.y, 32-bit index arithmetic inside it (an image has at most a few million values)
+    const int HW = H * W, n = blockIdx.y;
+    const unsigned per_img = (unsigned)A * HW * attrs;
+    (void)N;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < per_img; idx += gridDim.x * blockDim.x) {
+        const unsigned b = idx / (unsigned)attrs;
+        const int t = idx - b * attrs;
+        const int box = b;
+        const int a = box / HW, cell = box - a * HW;
+        const int gy = cell / W, gx = cell - gy * W;
         float v = head[((size_t)(n * H + gy) * W + gx) * ld + a * attrs + t];
         float r;
         if (t == 0) r = __fmul_rn(__fadd_rn(1.f / (1.f + expf(-v)), (float)gx), yp.s0);
@@ -235,9 +235,10 @@ void launch_yolo_decode(const View &head, float *out, int total_boxes, int box_o
     }
     int attrs = num_classes + 5;
     if (head.c != A * attrs) fail("yolo: head has %d channels, expected %d", head.c, A * attrs);
-    size_t total = (size_t)head.n * A * head.h * head.w * attrs;
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(256), 0, s, head.p, out, head.n, head.h, head.w, head.ld, A,
-                       attrs, total_boxes, box_off, yp);
+    const size_t per_img = (size_t)A * head.h * head.w * attrs;
+    if (per_img >= (1ull << 31)) fail("yolo: head too large for 32-bit indexing");
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((per_img + 255) / 256), head.n), dim3(256), 0, s, head.p, out, head.n, head.h, head.w,
+                       head.ld, A, attrs, total_boxes, box_off, yp);
     YDS_HIP(hipGetLastError());
 }
 
