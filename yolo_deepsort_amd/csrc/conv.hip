@@ -400,6 +400,7 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
     YDS_HIP(hipStreamSynchronize(s));
     int best = -1;
     float best_t = 0.f;
+    std::vector<float> times(cand.size());
     for (size_t i = 0; i < cand.size(); ++i) {
         float t = 1e30f;
         for (int r = 0; r < ROUNDS; ++r) {
@@ -407,8 +408,13 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
             YDS_HIP(hipEventElapsedTime(&ms, ev[(i * ROUNDS + r) * 2], ev[(i * ROUNDS + r) * 2 + 1]));
             t = fminf(t, ms / REPS);
         }
+        times[i] = t;
         if (best < 0 || t < best_t) { best = cand[i]; best_t = t; }
     }
+    // near ties (within 1.5 %, the run-to-run noise of this measurement) go to the window-resident kernel: it fetches each
+    // input pixel once instead of nine times, and a stable choice keeps per-tile statistics comparable between runs
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (cand[i] == kF32Variants + 8 && best != cand[i] && times[i] <= best_t * 1.015f) { best = cand[i]; best_t = times[i]; }
     for (auto &e : ev) (void)hipEventDestroy(e);
     if (best_us) *best_us = best_t * 1e3f;
     return best;
