@@ -5,8 +5,8 @@ network descriptions from somewhere.  Rather than carrying cfg files around,
 the graphs are described here as code (residual stages, CSP stages, SPP, PAN
 necks) and rendered to standard Darknet INI text that any Darknet-cfg parser
 accepts, including ``parse_model_config`` (reference
-``yolo3/utils/parse_config.py:1-19``).  ``tests/test_cfgs.py`` checks, when
-``/root/reference`` is present, that the rendered graphs equal
+``yolo3/utils/parse_config.py:1-19``).  ``tests/test_oracle_darknet.py`` checks the rendered graphs against
+``tests/golden/cfg_parse.json`` - the reference's ``parse_model_config`` output for
 ``config/{yolov3,yolov3-tiny,yolov4,yolov4-tiny}.cfg`` on every key the
 reference reads (``yolo3/models/models.py:29-97``).
 """
