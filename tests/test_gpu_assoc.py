@@ -327,6 +327,32 @@ def _lsap(c):
     return r[:m.value], k[:m.value]
 
 
+def test_tracker_grows_past_its_initial_capacity():
+    """300 detections in the first frame start 300 tracks: more than the initial 256 slots (capacity doubles in place),
+    and the next frames associate them (problem sizes beyond the single-wavefront LSAP)."""
+    from yolo_deepsort_amd.deep_sort import _TrackerHandle
+    from oracle import tracker as otrk
+    _lib()
+    rng = np.random.RandomState(3)
+    n = 300
+    trk = _TrackerHandle(0.3, 0.7, 30, 3, 30)
+    ora = otrk.TrackerOracle(**TRACE_PARAMS)
+    base = np.concatenate([rng.uniform(0, 1800, (n, 1)), rng.uniform(0, 900, (n, 1)), rng.uniform(40, 80, (n, 1)), rng.uniform(100, 200, (n, 1))], 1)
+    feats = rng.randn(n, 512).astype(F32)
+    feats /= np.linalg.norm(feats, axis=1, keepdims=True)
+    for t in range(5):
+        tlwh = (base + np.array([2.0 * t, 1.0 * t, 0, 0])).astype(F32)
+        f = (feats + 0.02 * rng.randn(n, 512)).astype(F32)
+        pay = (np.arange(n) % 3).astype(F32)
+        out = trk.step(tlwh, f, pay)
+        want = np.array(ora.update(tlwh, f, pay), np.int32).reshape(-1, 6)
+        st = trk.state()
+        assert np.array_equal(st["ids"], ora.state()["ids"]) and np.array_equal(st["state"], ora.state()["state"]), t
+        assert out.shape == want.shape and np.array_equal(out[:, 4:], want[:, 4:]), t
+        assert np.abs(out[:, :4] - want[:, :4]).max(initial=0) <= 1, t
+    assert len(st["ids"]) >= 300 and out.shape[0] > 250
+
+
 def test_lsap_bit_exact_vs_scipy_and_oracle():
     from scipy.optimize import linear_sum_assignment
     from oracle import clib
@@ -350,7 +376,9 @@ def test_lsap_bit_exact_vs_scipy_and_oracle():
         r2, c2 = clib.lsap(c)
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (trial, nr, nc)
         assert np.array_equal(r2, r1) and np.array_equal(c2, c1)
-    for shape in ((200, 150), (150, 200), (1, 300), (300, 1), (257, 257)):
+    # kernel forms: one wavefront (<= 64 columns, above), workgroup with state + cost in LDS (200 x 150), state in LDS and
+    # cost in global memory (500 x 400), state in the global scratch buffer (> ~3200 rows / columns: no size limit)
+    for shape in ((200, 150), (150, 200), (1, 300), (300, 1), (257, 257), (64, 64), (65, 64), (64, 65), (500, 400), (3300, 6), (5, 3400)):
         c = np.full(shape, 0.30001, F32)
         m = rng.rand(*shape) < 0.03
         c[m] = rng.rand(m.sum()) * 0.3

@@ -166,3 +166,38 @@ def test_frame_by_frame_device_crop_path_equals_host_feature_path():
         assert np.array_equal(got, want), t
         rows_seen += len(want)
     assert rows_seen > 50
+
+
+def test_pipeline_nms_workspace_overflow_redoes_the_batch():
+    """A threshold so low that a frame has more (box, class) candidates than the pipeline's NMS workspace (4096): the
+    workspace grows and the batch is redone instead of failing (the reference has no limit, model_build.py:93-121)."""
+    from oracle.darknet import DarknetOracle
+    from oracle.pipeline import run_stream
+    from yolo_deepsort_amd import _lib, pipeline as pl
+    from yolo_deepsort_amd.deep_sort import DeepSort
+    from yolo_deepsort_amd.models import Darknet
+    _lib.init(0)
+    cfg = cfgs.cfg_text("yolov3-tiny", 416, 416)
+    blob = synth.darknet_weights_blob(cfg, 0, -1.0)
+    net = Darknet(None, img_size=(416, 416), batch_max=2, cfg_text=cfg)
+    net.load_darknet_weights(None, blob=blob)
+    sd = synth.reid_state_dict(0)
+    ds = DeepSort(sd, use_cuda=True, **DS)
+    frames = np.random.RandomState(4).randint(0, 256, (4, 480, 640, 3)).astype(np.uint8)
+    conf = 0.3
+    ref_net = DarknetOracle(cfg, 416, is_text=True)
+    ref_net.load_weights_array(np.frombuffer(blob, dtype=F32, offset=20))
+    from oracle.resize import resize_bilinear_u8
+    x = resize_bilinear_u8(frames[0], (416, 416)).astype(F32).transpose(2, 0, 1)[None] / F32(255.)
+    pred = ref_net(x)[0]
+    n_cand = int(((pred[:, 5:] * pred[:, 4:5] > conf) & (pred[:, 4:5] > conf)).sum())
+    assert n_cand > 4096, n_cand                                    # the case this test is about
+    pipe = pl.Pipeline(net, ds, conf, 0.4, class_mask=[0, 2, 4])
+    dev = _lib.DeviceBuffer.from_array(frames)
+    got = pipe.step(dev.offset(0), 480, 640, 2, dev.offset(2 * frames[0].nbytes)) + pipe.step(dev.offset(2 * frames[0].nbytes), 480, 640, 2)
+    want = run_stream(ref_net, sd, DS, frames, None, conf=conf)
+    for t, (g, w) in enumerate(zip(got, want)):
+        w = np.array(w, np.int32).reshape(-1, 6)
+        assert g is not None and g.shape == w.shape, t
+        assert np.array_equal(g[:, 4:], w[:, 4:]), t
+        assert np.abs(g[:, :4] - w[:, :4]).max(initial=0) <= 1, t
