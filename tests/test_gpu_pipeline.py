@@ -111,7 +111,13 @@ def test_video_detector_batched_lookahead_equals_frame_by_frame():
         net.load_darknet_weights(None, blob=blob)
         vd = VideoDetector(net, f.name, thres=0.5, nms_thres=0.4, skip_frames=2, tracker=DeepSort(sd, use_cuda=True, **DS),
                            batch_frames=bf)
-        runs[bf] = [(img.shape, None if d is None else np.array(d, np.int32).reshape(-1, 6)) for img, d, _ in vd.detect(frames)]
+        out_npy = f.name + ".npy" if bf == 4 else None
+        runs[bf] = [(img.shape, None if d is None else np.array(d, np.int32).reshape(-1, 6)) for img, d, _ in vd.detect(frames, output_path=out_npy)]
+        if out_npy:
+            saved = np.load(out_npy)
+            os.unlink(out_npy)
+            assert saved.shape == (len(frames), 480, 640, 3)
+            assert (saved[-1] != frames[-1][:, :, ::-1]).any()          # overlay (boxes / FPS text) drawn on the BGR output
     os.unlink(f.name)
     assert len(runs[1]) == len(runs[4]) == len(frames)
     rows = 0

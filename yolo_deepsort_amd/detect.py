@@ -271,6 +271,43 @@ class VideoDetector:
             cur, cur_dev = nxt, nxt_dev
 
     def detect(self, video_path, output_path=None, skip_secs=0, real_show=False, show_fps=True):
+        """Generator of (bgr_image, hold_detections, actions) like video_detect.py:78-199.  output_path: every result is
+        also written - through cv2.VideoWriter when cv2 is installed, as one uint8 [N,H,W,3] array for a path ending in
+        ``.npy``; real_show needs cv2 (ignored without it); skip_secs needs a seekable cv2 capture (ignored otherwise)."""
+        writer, frames_out, cv2 = None, None, None
+        try:
+            import cv2 as _cv2
+            cv2 = _cv2
+        except ImportError:
+            pass
+        if output_path is not None:
+            if str(output_path).endswith(".npy"):
+                frames_out = []
+            elif cv2 is None:
+                raise IOError("writing %s needs cv2 (or use an .npy path)" % output_path)
+        try:
+            for result, det, actions in self._detect_impl(video_path, show_fps):
+                if frames_out is not None:
+                    frames_out.append(result.copy())
+                elif output_path is not None:
+                    if writer is None:
+                        fourcc = cv2.VideoWriter_fourcc(*self.fourcc) if isinstance(self.fourcc, str) else self.fourcc
+                        writer = cv2.VideoWriter(output_path, fourcc, 25, (result.shape[1], result.shape[0]))
+                    writer.write(result)
+                if real_show and cv2 is not None:
+                    cv2.imshow("result", result)
+                yield result, det, actions
+                if real_show and cv2 is not None and cv2.waitKey(1) & 0xFF == ord("q"):
+                    break
+        finally:
+            if writer is not None:
+                writer.release()
+            if frames_out is not None:
+                np.save(output_path, np.stack(frames_out, 0) if frames_out else np.zeros((0, 0, 0, 3), np.uint8))
+            if real_show and cv2 is not None:
+                cv2.destroyAllWindows()
+
+    def _detect_impl(self, video_path, show_fps=True):
         # (the tracker-side NMS option reorders detections on the host, so it keeps the frame-by-frame path)
         if (self.batch_frames > 1 and self.tracker is not None and self.image_detector.win_size is None
                 and getattr(self.tracker, "nms_max_overlap", 1) == 1):
