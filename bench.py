@@ -90,12 +90,14 @@ def main():
 
     import torch
     from yolo_deepsort_amd.dist import Ranks
-    ranks = Ranks("nccl")
+    # nccl = RCCL over xGMI (the real multi-GPU run).  YDS_DIST_BACKEND=gloo lets the N-rank path be exercised on a box whose
+    # ranks share one GPU (tests: YDS_DEVICE=0 for every rank) - RCCL refuses two ranks on one device
+    ranks = Ranks(os.environ.get("YDS_DIST_BACKEND", "nccl"))
     rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
 
     from yolo_deepsort_amd import _lib, pipeline as pl
     from yolo_deepsort_amd.workload import Workload
-    _lib.init(local_rank)
+    _lib.init(None if os.environ.get("YDS_DEVICE") else local_rank)
     lib = _lib.load()
 
     B, K, W = args.batch, args.steps, args.warmup

@@ -57,3 +57,19 @@ def test_two_ranks_use_two_gpus():
                           "--no-roofline"], capture_output=True, text=True, timeout=1200)
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and len(set(line["config"]["rank_pci_bus_ids"])) == 2, line
+
+
+def test_two_rank_bench_path_on_one_gpu():
+    """The N > 1 code path end to end on the 1-GPU box: two processes under torch.distributed.run, one stream per rank
+    (seeds 0 and 1), barriers + max-over-ranks timing + gathered device ids - with both ranks bound to GPU 0 and gloo for
+    the rendezvous (RCCL refuses two ranks on one device; the real run uses nccl and one GPU per rank)."""
+    env = dict(os.environ, YDS_DEVICE="0", YDS_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                          "--cpu-frames", "0", "--no-extras", "--no-roofline"], capture_output=True, text=True, timeout=1500, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-500:] + out.stderr[-1500:]          # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["streams"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["rank_devices"] == [0, 0] and line["value"] > 0
+    assert line["config"]["tracker_rows_out"] > 0                                                   # both streams produced rows
