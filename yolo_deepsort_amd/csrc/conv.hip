@@ -352,10 +352,11 @@ static std::string tune_key(const ConvArgs &a) {
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
     if (const char *f = getenv("YDS_CONV_FORCE")) {      // tuning aid: pin a variant id where it is applicable
         int v = atoi(f);
-        bool dma = v >= kF32Variants + 4 && v != kDirectVariant;
+        const bool f16v = v >= kF32Variants && v != kDirectVariant;
+        const bool presplit = f16v && (f16_variant_is_dma(v - kF32Variants) || f16_variant_is_win(v - kF32Variants));
         if (v == kDirectVariant && !conv_direct_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
-        if (v >= kF32Variants + 8 && v != kDirectVariant && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
-        if (!(dma && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
+        if (f16v && f16_variant_is_win(v - kF32Variants) && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
+        if (!(presplit && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
     const std::string key = tune_key(a);
     auto &cache = tune_cache();
@@ -382,9 +383,11 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
             v = kDirectVariant;
         }
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
-        if (v != kDirectVariant && v >= kF32Variants + 4 && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // LDS-DMA tiles need a pre-split input
-        if (v >= kF32Variants + 8 && v != kDirectVariant && !conv_win_applicable(make_conv_args(a))) continue;
-        if (v > kF32Variants + 8 && v != kDirectVariant && a.y.c > 64) continue;       // 64-wide tiles are for 64-filter layers
+        const int fv = v - kF32Variants;                // f16x3 variant index (meaningful for kF32Variants <= v < kDirectVariant)
+        const bool f16v = v >= kF32Variants && v != kDirectVariant;
+        if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv)) && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // need a pre-split input
+        if (f16v && f16_variant_is_win(fv) && !conv_win_applicable(make_conv_args(a))) continue;
+        if (f16v && f16_variant_is_win(fv) && fv > 8 && a.y.c > 64) continue;          // 64-wide window tiles are for 64-filter layers
         cand.push_back(v);
     }
     constexpr int ROUNDS = 2, REPS = 6;

@@ -258,7 +258,7 @@ constexpr size_t dma_smem_bytes(int BM, int BN, int NS) {
     return (size_t)NS * (BM + BN) * 128 > conv_stage_bytes(BM, BN) ? (size_t)NS * (BM + BN) * 128 : conv_stage_bytes(BM, BN);
 }
 template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS>
-__global__ __launch_bounds__(WM * WN * 64, (dma_smem_bytes(BM, BN, NS) <= 80 * 1024 && WM * WN == 4) ? 2 : 1)
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN != 4 || dma_smem_bytes(BM, BN, NS) > 80 * 1024) ? 1 : (dma_smem_bytes(BM, BN, NS) <= 53 * 1024 ? 3 : 2))
 void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -529,7 +529,8 @@ const char *conv_f16x3_variant_name(int v) {
     static const char *names[kF16Variants] = {"conv_igemm_f16x3<128,128>", "conv_igemm_f16x3<64,128>", "conv_igemm_f16x3<128,64>",
                                               "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,2x2,2>", "conv_igemm_f16x3_dma<256,128,4x2,3>",
                                               "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>", "conv3x3_f16x3_win<256,128,4x2>",
-                                              "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>"};
+                                              "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>",
+                                              "conv_igemm_f16x3_dma<128,64,2x2,2>", "conv_igemm_f16x3_dma<64,128,2x2,2>"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
 }
 
@@ -545,7 +546,11 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s) {
         case 7: launch_cfg_dma<128, 128, 2, 2, 3>(k, s); break;
         case 8: launch_conv_win(k, 0, s); break;
         case 9: launch_conv_win(k, 1, s); break;
-        default: launch_conv_win(k, 2, s); break;
+        case 10: launch_conv_win(k, 2, s); break;
+        // small LDS-DMA tiles (48 KB of LDS: three workgroups per CU): layers whose 128x128 tile count leaves a long tail -
+        // the 1x1 layers at 76^2 / 38^2 / 19^2 run 1.4 rounds of 128x128 tiles on 512 slots, i.e. pay for 2
+        case 11: launch_cfg_dma<128, 64, 2, 2, 2>(k, s); break;
+        default: launch_cfg_dma<64, 128, 2, 2, 2>(k, s); break;
     }
 }
 
