@@ -224,8 +224,8 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     for (int b = 0; b < B_INST; ++b) b_piece(0, 0, 0, b);
 #pragma unroll
     for (int b = 0; b < B_INST; ++b) b_piece(0, 1, 1, b);
-    wait_vmcnt<0>();
-    __syncthreads();                                            // window 0, stages 0 and 1 and the zero row are in LDS
+    wait_vmcnt<B_INST>();                                       // stage 1 may still be in flight: step 0's mid-step wait covers it
+    __syncthreads();                                            // window 0, stage 0 and the zero row are in LDS
     tap_addr(0, 0);
 #pragma unroll
     for (int f = 0; f < NF; ++f) frag_read(bring, 0, f);
