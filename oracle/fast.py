@@ -25,7 +25,7 @@ _ACT = {"linear": 0, "leaky": 1, "mish": 2, "relu": 3}
 def build(force=False):
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(_SRC):
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", _SRC, "-o", _SO, "-lm"])
+        subprocess.check_call(["gcc", "-O3", "-mavx2", "-mfma", "-fopenmp", "-fPIC", "-shared", "-std=c11", _SRC, "-o", _SO, "-lm"])
     return _SO
 
 

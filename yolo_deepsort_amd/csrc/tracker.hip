@@ -347,15 +347,8 @@ __device__ __forceinline__ void lsap_wave_min(double &v, int &key) {
 // GSTATE: solver state in the global scratch buffer (huge problems) instead of LDS - a compile-time choice, so that the LDS
 // version addresses its state with ds_read / ds_write (a pointer that may be either makes every access a flat_load)
 template <bool GSTATE, bool COST_LDS>
-__global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr0, int nc0, const int *dims_p, int *row_out, int *col_out,
-                                                       int *n_out, char *state_global) {
-    if (dims_p) { nr0 = dims_p[0]; nc0 = dims_p[1]; }
+__device__ __forceinline__ void lsap_wg_solve(const float *cost, int nr0, int nc0, int *row_out, int *col_out, int *n_out, char *state_global) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (nr0 <= 0 || nc0 <= 0) {                                  // linear_assignment.py:48-49 early-out
-        if (tid == 0 && n_out) *n_out = 0;
-        return;
-    }
-    if (max(nr0, nc0) <= LSAP_WAVE_COLS) return;                 // solved by lsap_wave_kernel (launched in front of this one)
     const bool transpose = nc0 < nr0;
     const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
     extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
@@ -463,6 +456,23 @@ __global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr
         for (int r = tid; r < nr; r += LSAP_NT) { row_out[r] = r; col_out[r] = col4row[r]; }
     }
     if (tid == 0 && n_out) *n_out = nr;
+}
+
+// The launch sizes its LDS from host-side upper bounds (inside a batch the live-track count is only bounded by T + sum D);
+// whether the cost matrix is copied into LDS is decided HERE from the actual sizes - a 200 x 150 problem launched under a
+// bound of 2600 x 150 must not fall back to reading its costs from global memory in the Dijkstra step.
+template <bool GSTATE>
+__global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr0, int nc0, const int *dims_p, int *row_out, int *col_out,
+                                                       int *n_out, char *state_global, int smem_bytes) {
+    if (dims_p) { nr0 = dims_p[0]; nc0 = dims_p[1]; }
+    if (nr0 <= 0 || nc0 <= 0) {                                  // linear_assignment.py:48-49 early-out
+        if (threadIdx.x == 0 && n_out) *n_out = 0;
+        return;
+    }
+    if (max(nr0, nc0) <= LSAP_WAVE_COLS) return;                 // solved by lsap_wave_kernel (launched in front of this one)
+    const size_t state = GSTATE ? 0 : (size_t)max(nr0, nc0) * LSAP_STATE_BYTES;
+    if (state + (size_t)nr0 * nc0 * sizeof(float) <= (size_t)smem_bytes) lsap_wg_solve<GSTATE, true>(cost, nr0, nc0, row_out, col_out, n_out, state_global);
+    else lsap_wg_solve<GSTATE, false>(cost, nr0, nc0, row_out, col_out, n_out, state_global);
 }
 
 // ---- single-wavefront form for problems with at most 256 columns (after the tall->wide transposition): every lane keeps
@@ -642,22 +652,22 @@ static void launch_lsap(const float *cost_dev, int nr_max, int nc_max, const int
     const size_t n = (size_t)std::max(std::max(nr_max, nc_max), 1);
     const size_t state = n * LSAP_STATE_BYTES, cost_bytes = (size_t)nr_max * nc_max * sizeof(float);
     const bool state_lds = state <= LSAP_LDS_MAX;
-    const bool cost_lds = (state_lds ? state : 0) + cost_bytes <= LSAP_LDS_MAX;
-    const size_t smem = (state_lds ? state : 0) + (cost_lds ? cost_bytes : 0);
+    // LDS: the state of the largest possible problem, plus the cost matrix if the bounds allow it; when they do not, the whole
+    // LDS is requested anyway and the kernel decides from the actual sizes
+    const size_t smem = state_lds ? std::min(state + cost_bytes, LSAP_LDS_MAX) : std::min(cost_bytes, LSAP_LDS_MAX);
     if (!state_lds && scratch.n < state) {
         YDS_HIP(hipStreamSynchronize(s));                        // nothing may still use the old scratch
         scratch.alloc(state);
     }
     static bool attr_set = false;
     if (!attr_set) {
-        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
-        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
-        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
+        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
         attr_set = true;
     }
-    auto kern = state_lds ? (cost_lds ? lsap_kernel<false, true> : lsap_kernel<false, false>) : lsap_kernel<true, false>;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(LSAP_NT), state_lds ? smem : 0, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev, n_out_dev,
-                       state_lds ? (char *)nullptr : scratch.p);
+    auto kern = state_lds ? lsap_kernel<false> : lsap_kernel<true>;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(LSAP_NT), smem, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev, n_out_dev,
+                       state_lds ? (char *)nullptr : scratch.p, (int)smem);
     YDS_HIP(hipGetLastError());
 }
 
