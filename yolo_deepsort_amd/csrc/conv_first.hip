@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_direct(ConvKernelArgs p, int 
                 const bool odd = q & 1;
                 union { h16x4 h; int i[2]; } send, recv;
                 send.h = odd ? hi : lo;
-                recv.i[0] = __shfl_xor(send.i[0], 1);
-                recv.i[1] = __shfl_xor(send.i[1], 1);
+                recv.i[0] = __builtin_amdgcn_update_dpp(send.i[0], send.i[0], 0xB1, 0xF, 0xF, false);   // lane ^ 1 (DPP quad_perm [1,0,3,2])
+                recv.i[1] = __builtin_amdgcn_update_dpp(send.i[1], send.i[1], 0xB1, 0xF, 0xF, false);
                 union { h16x4 h[2]; float4 f; } out;
                 out.h[0] = odd ? recv.h : hi;
                 out.h[1] = odd ? lo : recv.h;
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(MP_NT, 1) void conv3x3_rgb_pool_mfma(ConvKernelArgs
                 const bool odd = cq & 1;
                 union { h16x4 h; int i[2]; } send, recv;
                 send.h = odd ? hi : lo;
-                recv.i[0] = __shfl_xor(send.i[0], 1);
-                recv.i[1] = __shfl_xor(send.i[1], 1);
+                recv.i[0] = __builtin_amdgcn_update_dpp(send.i[0], send.i[0], 0xB1, 0xF, 0xF, false);   // lane ^ 1 (DPP quad_perm [1,0,3,2])
+                recv.i[1] = __builtin_amdgcn_update_dpp(send.i[1], send.i[1], 0xB1, 0xF, 0xF, false);
                 union { h16x4 h[2]; float4 f; } out;
                 out.h[0] = odd ? recv.h : hi;
                 out.h[1] = odd ? lo : recv.h;
