@@ -11,8 +11,17 @@ Rank 0 prints ONE JSON line:
   value_with_upload   the same K steps with the frames handed over as pinned HOST memory and uploaded inside the step
                       (yds_pipeline_step_host: copy stream, double buffered) - the PCIe-inclusive rate
   value_f32_math      a short run of the same workload on the exact-fp32 MFMA kernels (dtype of `value` is f16x3)
-  roofline            dominant conv kernel vs its MFMA bound, HIP-event timed on the detector's stream
+  value_frame_by_frame  one frame in, one result out (batch_frames = 1, nothing enqueued ahead: the reference's own loop,
+                      video_detect.py:124-157); value_frame_by_frame_lookahead1 hands the next frame over one step early
+  roofline            dominant conv kernel vs its MFMA bound: HIP event pairs around every conv launch on the detector's
+                      stream, recorded (without host synchronisation) over a repeat of the SAME K timed steps - ReID and
+                      association streams live, next pass prefetched - so `frac` is the overlapped, in-pipeline figure;
+                      `frac_isolated` comes from two non-prefetched steps (conv stream alone).  `all_conv_kernels` adds the
+                      per-launch attainable bound max(flops / MFMA peak, bytes / 6.29 TB/s) so HBM-bound 1x1 layers are
+                      priced against the right roof.
   cpu_baseline        the oracle pipeline (C + OpenMP / BLAS) on the host cores over a bounded sample of the same stream
+N > 1: every rank runs its own stream (cfg4 = cfg3 per rank, seeds = rank); after each step the ranks all-gather their
+result rows ({count, rows[256][6]} per frame, RCCL through libydsort's yds_comm_*) so rank 0 holds every stream's output.
 """
 
 import argparse
@@ -43,22 +52,45 @@ def cpu_baseline(config, n_frames):
     return rec
 
 
-def timed_steps(wl, ranks, sync, K, W, first, host_frames):
-    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks."""
+def timed_steps(wl, ranks, sync, K, W, first, host_frames, lookahead=True, keep=None):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks.
+    Every step ends with the exchange step of the multi-GPU run: the all-gather of this batch's result rows (no-op for one rank)."""
     for i in range(first, first + W):
-        wl.step(i, prefetch=i + 1 < first + W, host_frames=host_frames)   # nothing of the timed region is enqueued before the clock starts
+        wl.step(i, prefetch=lookahead and i + 1 < first + W, host_frames=host_frames)   # nothing of the timed region is enqueued before the clock starts
     sync()
     ranks.barrier()
     sync()
     t0 = time.perf_counter()
     n_out = 0
     for i in range(first + W, first + W + K):
-        outs = wl.step(i, prefetch=i + 1 < first + W + K, host_frames=host_frames)   # exactly K detector passes inside the timed region
-        n_out += sum(0 if o is None else len(o) for o in outs)
+        outs = wl.step(i, prefetch=lookahead and i + 1 < first + W + K, host_frames=host_frames)   # exactly K detector passes inside the timed region
+        streams = ranks.gather_rows(outs)
+        n_out += sum(0 if o is None else len(o) for st in streams for o in st)
+        if keep is not None:
+            keep.append(streams)
     sync()
     ranks.barrier()
     sync()
     return ranks.max_over_ranks(time.perf_counter() - t0), n_out
+
+
+def conv_roofline(variants, peak, args_half):
+    """Per-variant totals -> the dominant variant's record + the all-conv record (achieved, frac, frac_of_attainable)."""
+    live = [v for v in variants if v["launches"]]
+    if not live:
+        return None, None
+    dom = max(live, key=lambda v: v["us"])
+    tot_us = sum(v["us"] for v in live)
+    tot_fl = sum(v["flops"] for v in live)
+    tot_by = sum(v["bytes"] for v in live)
+    tot_at = sum(v["attainable_us"] for v in live)
+    rec = dict(kernel=dom["name"], achieved=dom["flops"] / dom["us"] / 1e6, avg_launch_us=dom["us"] / dom["launches"], launches=int(dom["launches"]),
+               flops_per_launch=dom["flops"] / dom["launches"], bytes_per_launch=dom["bytes"] / dom["launches"],
+               share_of_conv_time=dom["us"] / tot_us, frac_of_attainable=dom["attainable_us"] / dom["us"])
+    rec["frac"] = rec["achieved"] / peak
+    allc = dict(achieved=tot_fl / tot_us / 1e6, frac=tot_fl / tot_us / 1e6 / peak, hbm_tb_s=tot_by / tot_us / 1e6,
+                attainable_us=tot_at, measured_us=tot_us, frac_of_attainable=tot_at / tot_us)
+    return rec, allc
 
 
 def main():
@@ -67,7 +99,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="frames per step (detector batch)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg4 = configs[3]: yolov4 + DeepSORT, one stream per GPU (seeds = rank)")
+    ap.add_argument("--seed-base", type=int, default=0, help="stream seed of rank r = seed-base + r")
+    ap.add_argument("--dump-rows", default=None, help="rank 0 saves every stream's tracker rows of the timed steps (npz: s<stream>_k<step>_f<frame>)")
+    ap.add_argument("--latency-steps", type=int, default=150, help="frames of the frame-by-frame legs (0 = skip)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
@@ -88,32 +124,39 @@ def main():
     if world_env != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}; launch one rank per GPU")
 
-    import torch
     from yolo_deepsort_amd.dist import Ranks
-    # nccl = RCCL over xGMI (the real multi-GPU run).  YDS_DIST_BACKEND=gloo lets the N-rank path be exercised on a box whose
-    # ranks share one GPU (tests: YDS_DEVICE=0 for every rank) - RCCL refuses two ranks on one device
+    # nccl = RCCL over xGMI through libydsort's yds_comm_* (the real multi-GPU run).  YDS_DIST_BACKEND=gloo lets the N-rank path be
+    # exercised on a box whose ranks share one GPU (tests: YDS_DEVICE=0 for every rank) - RCCL refuses two ranks on one device
     ranks = Ranks(os.environ.get("YDS_DIST_BACKEND", "nccl"))
-    rank, local_rank, world = ranks.rank, ranks.local_rank, ranks.world
+    rank, world = ranks.rank, ranks.world
 
     from yolo_deepsort_amd import _lib, pipeline as pl
     from yolo_deepsort_amd.workload import Workload
-    _lib.init(None if os.environ.get("YDS_DEVICE") else local_rank)
+    _lib.init()                    # YDS_DEVICE, else LOCAL_RANK (ordinal 0 when the launcher masks one device per rank)
     lib = _lib.load()
+    ranks.connect()                # RCCL communicator on the bound device (N > 1)
 
     B, K, W = args.batch, args.steps, args.warmup
-    wl = Workload(args.config, B, seed=ranks.stream_seed(), half=args.half)
+    wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
     cfg = wl.cfg
     wl.to_device()
 
     def sync():
         _lib.check(lib.yds_device_sync())
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
 
     # ---- the metric: frames resident in HBM
-    dt, n_out = timed_steps(wl, ranks, sync, K, W, 0, host_frames=False)
-    n_out = int(ranks.sum_over_ranks(n_out))
+    kept = [] if args.dump_rows else None
+    dt, n_out = timed_steps(wl, ranks, sync, K, W, 0, host_frames=False, keep=kept)     # n_out: rows of ALL streams (gathered on every rank)
+    if kept is not None and rank == 0:
+        import numpy as np
+        arrays = {}
+        for k, streams in enumerate(kept):
+            for st, frames in enumerate(streams):
+                for f, o in enumerate(frames):
+                    arrays[f"s{st}_k{k}_f{f}"] = np.full((1, 6), -1, np.int32) if o is None else np.asarray(o, np.int32).reshape(-1, 6)
+        np.savez(args.dump_rows, **arrays)
     rank_devices = ranks.gather_objects((_lib.current_device(), _lib.pci_bus_id()))
+    flops_frame = wl.flops_per_frame()
     stage = wl.pipe.stage_us()
     math_name = {0: "f32", 1: "f16x3", 2: "f16"}[lib.yds_get_conv_math()] if not args.half else "f16"
 
@@ -123,45 +166,68 @@ def main():
         dt_up, _ = timed_steps(wl, ranks, sync, K, W, W + K, host_frames=True)
 
     roofline, variants = None, None
-    if rank == 0 and not args.no_roofline:
-        # HIP events recorded around every conv launch on the detector's stream, over extra steps of the
-        # same workload (kept out of the throughput region because each pair forces a host sync)
+    if not args.no_roofline:
+        # (every rank runs the leg - its steps contain the exchange step - rank 0 reports)
+        f16x3 = lib.yds_get_conv_math() == 1 and not args.half
+        peak = PEAK_F16_MFMA_TFLOPS / 3 if f16x3 else (PEAK_F16_MFMA_TFLOPS if args.half else PEAK_F32_MFMA_TFLOPS)
+        # (a) the SAME K timed steps once more with an event pair around every conv launch (no host sync inside the pass)
         pl.conv_timing(wl.net, 1)
-        base = 2 * (W + K)
+        dt_ev, _ = timed_steps(wl, ranks, sync, K, W, 2 * (W + K), host_frames=False)
+        variants = pl.conv_timing(wl.net, 2)
+        dom, allc = conv_roofline(variants, peak, args.half)
+        # (b) two non-prefetched steps: the conv stream alone (ReID / association of a step run after its detector pass)
+        pl.conv_timing(wl.net, 1)
+        base = 3 * (W + K)
         for i in range(base, base + 2):
             wl.step(i, prefetch=False)
-        variants = pl.conv_timing(wl.net, 2)
-        dom = max(variants, key=lambda v: v["us"])
-        if dom["launches"]:
-            avg_us = dom["us"] / dom["launches"]
-            achieved = dom["flops"] / dom["us"] / 1e6        # TFLOP/s of algorithmic (fp32-equivalent) conv work
-            # f16x3 spends 3 fp16 MFMAs per multiply-accumulate, so its matrix-pipe bound is the dense fp16 peak / 3
-            f16x3 = "f16x3" in dom["name"] and not args.half
-            peak = PEAK_F16_MFMA_TFLOPS / 3 if f16x3 else (PEAK_F16_MFMA_TFLOPS if args.half else PEAK_F32_MFMA_TFLOPS)
-            tot_us = sum(v["us"] for v in variants)
-            tot_fl = sum(v["flops"] for v in variants)
-            roofline = dict(bound="mfma", kernel=dom["name"], achieved=round(achieved, 2), peak=round(peak, 1),
-                            unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
+        iso_variants = pl.conv_timing(wl.net, 2)
+        iso_dom, iso_all = conv_roofline(iso_variants, peak, args.half)
+        if rank == 0 and dom is not None:
+            iso_same = next((v for v in iso_variants if v["name"] == dom["kernel"] and v["launches"]), None)
+            roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(dom["achieved"], 2), peak=round(peak, 1),
+                            unit="TFLOP/s", frac=round(dom["frac"], 4), traffic=None,
+                            timing="HIP event pairs on the detector stream over a repeat of the K timed steps (prefetched, ReID / association streams live)",
+                            frac_isolated=None if iso_same is None else round(iso_same["flops"] / iso_same["us"] / 1e6 / peak, 4),
                             peak_note=("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
                                        else ("dense fp16 MFMA" if args.half else "fp32-input MFMA, 64 FLOP/clk/SIMD")),
-                            frac_of_fp32_mfma_peak=round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                            frac_of_fp32_mfma_peak=round(dom["achieved"] / PEAK_F32_MFMA_TFLOPS, 4),
                             # pure-MFMA loop on random fp16 data, sustained (power limited): profiles/r01_ablation_dma.txt #6
-                            frac_of_measured_mfma_ceiling=round(achieved / (MEASURED_F16_MFMA_TFLOPS / 3 if f16x3 else PEAK_F32_MFMA_TFLOPS), 4),
-                            avg_launch_us=round(avg_us, 2), launches=int(dom["launches"]),
-                            flops_per_launch=dom["flops"] / dom["launches"],
-                            share_of_conv_time=round(dom["us"] / tot_us, 4),
-                            all_conv_kernels=dict(achieved=round(tot_fl / tot_us / 1e6, 2), frac=round(tot_fl / tot_us / 1e6 / peak, 4),
-                                                  us_per_frame=round(tot_us / (2 * B), 1)))
+                            frac_of_measured_mfma_ceiling=round(dom["achieved"] / (MEASURED_F16_MFMA_TFLOPS / 3 if f16x3 else PEAK_F32_MFMA_TFLOPS), 4),
+                            frac_of_attainable=round(dom["frac_of_attainable"], 4),
+                            avg_launch_us=round(dom["avg_launch_us"], 2), launches=dom["launches"],
+                            flops_per_launch=dom["flops_per_launch"], algorithmic_bytes_per_launch=round(dom["bytes_per_launch"]),
+                            share_of_conv_time=round(dom["share_of_conv_time"], 4),
+                            fps_with_conv_events=round(ranks.total_frames(K, B) / dt_ev, 2),
+                            all_conv_kernels=dict(achieved=round(allc["achieved"], 2), frac=round(allc["frac"], 4),
+                                                  frac_isolated=None if iso_all is None else round(iso_all["frac"], 4),
+                                                  algorithmic_hbm_tb_s=round(allc["hbm_tb_s"], 3),
+                                                  attainable="sum over launches of max(flops / MFMA bound, algorithmic bytes / 6.29 TB/s)",
+                                                  frac_of_attainable=round(allc["frac_of_attainable"], 4),
+                                                  us_per_frame=round(allc["measured_us"] / (K * B), 1)))
             # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
             # the committed rocprofv3 --pmc passes over this same command (tools/profile_bench.sh, PMC=1)
-            for rnd in ("r02", "r01"):
-                tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{args.config}.json")
+            for rnd in ("r03", "r02", "r01"):
+                cfg_key = "cfg3" if args.config == "cfg4" else args.config
+                tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{cfg_key}.json")
                 if os.path.exists(tpath) and B == 16:
-                    rec = json.load(open(tpath))["kernels"].get(dom["name"])
+                    rec = json.load(open(tpath))["kernels"].get(dom["kernel"])
                     if rec:
                         roofline["traffic"] = round(rec["hbm_bytes_per_launch"])
                         roofline["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/" + os.path.basename(tpath) + ")"
                         break
+
+    # ---- frame by frame: batch_frames = 1 (the reference's loop: one frame in, one result out)
+    fbf, fbf_ahead, fbf_stage = None, None, None
+    if args.latency_steps > 0 and not args.half:
+        wl1 = Workload(args.config, 1, seed=ranks.stream_seed(args.seed_base), n_distinct=64)
+        wl1.to_device()
+        n1 = args.latency_steps
+        dt1, _ = timed_steps(wl1, ranks, sync, n1, 20, 0, host_frames=False, lookahead=False)
+        fbf_stage = wl1.pipe.stage_us()
+        dt1a, _ = timed_steps(wl1, ranks, sync, n1, 20, n1 + 20, host_frames=False, lookahead=True)
+        fbf, fbf_ahead = ranks.total_frames(n1, 1) / dt1, ranks.total_frames(n1, 1) / dt1a
+        del wl1
+        sync()
 
     # ---- exact-fp32 kernels, short run (the network is re-planned: tensor formats depend on the conv math)
     f32_fps = None
@@ -169,7 +235,7 @@ def main():
         del wl
         sync()
         lib.yds_set_conv_math(0)
-        wl32 = Workload(args.config, B, seed=ranks.stream_seed())
+        wl32 = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base))
         wl32.to_device()
         k32 = max(3, min(K, 6))
         dt32, _ = timed_steps(wl32, ranks, sync, k32, 2, 0, host_frames=False)
@@ -178,13 +244,11 @@ def main():
         lib.yds_set_conv_math(1)
 
     cpu = None
-    if rank == 0 and args.cpu_frames > 0:
-        cpu = cpu_baseline(args.config, args.cpu_frames)
+    if rank == 0 and world == 1 and args.cpu_frames > 0:      # rank 0 at N = 1 only (bench contract)
+        cpu = cpu_baseline("cfg3" if args.config == "cfg4" else args.config, args.cpu_frames)
 
     if rank == 0:
         frames_total = ranks.total_frames(K, B)
-        per_frame = cfg["visible"] or cfg["persons"]
-        flops_frame = None
         line = {
             "metric": "end-to-end frames/sec (detect+ReID+assoc), 608x608",
             "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -193,11 +257,19 @@ def main():
             "config": {"workload": cfg["workload"], "frames_per_step": B, "streams": world, "frame": "1920x1080x3 u8",
                        "frames_in": "resident in HBM", "tracker_rows_out": n_out, "parallelism": f"stream-per-gpu x{world}",
                        "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices]},
+            "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_with_upload is the PCIe-inclusive rate",
             "value_with_upload": None if dt_up is None else round(frames_total / dt_up, 2),
             "value_with_upload_note": "same K steps, frames handed over as pinned host memory and uploaded inside the step (copy stream, double buffered)",
             "value_f32_math": None if f32_fps is None else round(f32_fps, 2),
+            "value_frame_by_frame": None if fbf is None else round(fbf, 2),
+            "value_frame_by_frame_lookahead1": None if fbf_ahead is None else round(fbf_ahead, 2),
+            "value_frame_by_frame_note": "batch_frames = 1: one frame in, one result out, nothing enqueued ahead (video_detect.py:124-157); "
+                                         "lookahead1 = the next frame is handed over one step early (its detector pass overlaps this frame's association)",
+            "stage_us_frame_by_frame": None if fbf_stage is None else {k: round(v, 1) for k, v in fbf_stage.items()},
+            "exchange": None if world == 1 else "all-gather of {count, rows[256][6]} per frame per rank after every step (%s)" % (
+                "RCCL via yds_comm_*" if ranks.comm is not None else "gloo"),
             "stage_us_last_step": {k: round(v, 1) for k, v in stage.items()},
-            "algorithmic_gflop_per_frame": round((140.692 if cfg["net"] == "yolov3" else 128.389) + per_frame * 2.2429, 2),
+            "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
             "roofline": roofline, "conv_variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

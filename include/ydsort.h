@@ -31,6 +31,7 @@ typedef struct yds_net yds_net;     /* Darknet detector      (yolo3/models/model
 typedef struct yds_reid yds_reid;   /* ReID extractor        (deep_sort/deep/feature_extractor.py) */
 typedef struct yds_trk yds_trk;     /* DeepSORT tracker      (deep_sort/sort/tracker.py:8-176)      */
 typedef struct yds_pipe yds_pipe;   /* detect+ReID+associate (yolo3/detect/video_detect.py:134-157) */
+typedef struct yds_comm yds_comm;   /* RCCL communicator of the stream-sharded multi-GPU run (no reference counterpart) */
 
 /* ---- runtime -------------------------------------------------------------------------- */
 /* Binds the PROCESS to one GPU (hipSetDevice + gfx950 check).  Multi-GPU runs are one process per GPU (bench.py /
@@ -182,6 +183,8 @@ int yds_tracker_nms(const float *tlwh_host, const int32_t *order_host, int D, do
 int yds_tracker_num_tracks(const yds_trk *);
 int yds_tracker_get_state(yds_trk *, int32_t *ids, int32_t *state, int32_t *tsu, int32_t *hits,
                           float *mean8, float *cov64, int cap, int *T);
+/* Track.payload of every live track, in track-list order (deep_sort/sort/track.py:77,141: the class id the demo passes) */
+int yds_tracker_get_payload(yds_trk *, float *payload, int cap);
 int yds_tracker_last_unmatched(yds_trk *, int32_t *um_tracks, int cap_t, int *n_t,
                                int32_t *um_dets, int cap_d, int *n_d);
 /* stand-alone association primitives (parity tests call these through the C ABI) */
@@ -192,6 +195,12 @@ int yds_kalman_predict(float *mean_host, float *cov_host, int T);
 int yds_kalman_update(float *mean_host, float *cov_host, const float *xyah_host, int M);
 int yds_kalman_gating(const float *mean_host, const float *cov_host, int T, const float *xyah_host, int D,
                       float *out_TxD_host);
+/* KalmanFilter.gating_distance with both settings of only_position (kalman_filter.py:206-256; 4 dof: torch.inverse form),
+ * KalmanFilter.initiate from (x, y, a, h) rows (:54-87) and KalmanFilter.project (:125-158: mean [n,4], covariance [n,4,4]) */
+int yds_kalman_gating_ex(const float *mean_host, const float *cov_host, int T, const float *xyah_host, int D, int only_position,
+                         float *out_TxD_host);
+int yds_kalman_initiate(const float *xyah_host, int n, float *mean_host, float *cov_host);
+int yds_kalman_project(const float *mean_host, const float *cov_host, int n, float *mean4_host, float *cov16_host);
 int yds_iou_cost(const float *track_tlwh_host, int T, const float *det_tlwh_host, int D, float *out_TxD_host);
 int yds_cosine_min_cost(const float *gallery_host, const int32_t *seg_offsets_host, int T,
                         const float *feats_host, int D, int dim, float *out_TxD_host);
@@ -226,6 +235,11 @@ int yds_pipeline_stage_us(yds_pipe *, float *us5);
  * duration in us, launch count and algorithmic flops, measured with HIP events recorded around every
  * launch on the handle's stream.  mode 1 = zero the counters and start timing, 2 = stop, 0 = read. */
 int yds_conv_timing(yds_net *, int mode, double *total_us, int64_t *launches, double *flops);
+/* same, plus per variant the algorithmic HBM bytes (input, weights and residual read once, output written once; 4 B per
+ * channel) and the summed per-launch attainable time max(flops / MFMA bound of the arithmetic, bytes / 6.29 TB/s) in us.
+ * The event pairs are recorded without any host synchronisation and resolved by mode 0 / 2, so a timed pass runs exactly
+ * like an untimed one (other streams live). */
+int yds_conv_timing_ex(yds_net *, int mode, double *total_us, int64_t *launches, double *flops, double *bytes, double *attainable_us);
 int yds_conv_num_variants(void);
 /* Arithmetic of the conv kernels: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = f16x3, a two-term fp16
  * split of both operands on v_mfma_f32_32x32x16_f16 with fp32 accumulation (fp32-class accuracy, ~1e-6
@@ -244,6 +258,31 @@ int yds_debug_prof(uint64_t *out8, int reset);
  * (res_mode 0 none, 1 after the activation, 2 before it), y NCHW [n,cout,ho,wo]. */
 int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int res_mode,
                  const float *x_nhwc, const float *w_okkc, const float *bias, const float *res_nhwc, float *y_nchw);
+
+/* ---- multi-GPU exchange step ------------------------------------------------------
+ * The reference is single-GPU; what shards is the video stream: every stream owns a tracker (DeepSort.clone(),
+ * deep_sort/deep_sort.py:41-44), so rank r runs stream r on GPU r with replicated weights and the only exchange is
+ * rank 0 collecting every stream's int32 rows.  These entries run RCCL directly (ncclCommInitRank / ncclAllGather /
+ * ncclAllReduce over xGMI) on the device bound by yds_init; librccl is opened lazily by yds_comm_unique_id /
+ * yds_comm_create.  The launcher distributes the 128-byte id (rank 0 creates it) by any host-side channel.
+ *   yds_comm_allgather_rows: per frame b of a batch the fixed block {int32 count; int32 rows[YDS_COMM_MAX_ROWS][6]}
+ *     (count = counts_host[b], -1 = detector returned None) is gathered from every rank:
+ *     all_host = int32 [world][batch][1 + YDS_COMM_MAX_ROWS*6], rank-major.
+ *   yds_comm_allreduce_f64: in-place sum (op 0) / max (op 1) over ranks of n doubles (frame counters, the job time).
+ *   yds_comm_barrier: every rank has arrived (an all-reduce of one element). */
+#define YDS_COMM_ID_BYTES 128
+#define YDS_COMM_MAX_ROWS 256
+int yds_comm_unique_id(void *id128_out);
+yds_comm *yds_comm_create(const void *id128, int world, int rank);
+void yds_comm_destroy(yds_comm *);
+int yds_comm_world(const yds_comm *);
+int yds_comm_rank(const yds_comm *);
+int yds_comm_rccl_version(void);
+int yds_comm_allgather(yds_comm *, const void *send_host, size_t bytes, void *recv_host);
+int yds_comm_allgather_dev(yds_comm *, const void *send_dev, size_t bytes, void *recv_dev);
+int yds_comm_allgather_rows(yds_comm *, const int32_t *out6_host, int cap, const int32_t *counts_host, int batch, int32_t *all_host);
+int yds_comm_allreduce_f64(yds_comm *, double *vals_host, int n, int op);
+int yds_comm_barrier(yds_comm *);
 
 #ifdef __cplusplus
 }

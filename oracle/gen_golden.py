@@ -712,13 +712,60 @@ def run_reference_stream(ns, cfg_name, n_frames, seed=0, sample=512):
 
 def gen_bench_shape(ns):
     """VERDICT r1 #2: parity AT the benchmarked shape (batch 16 x 1080p, 608x608, 2 steps) from the reference itself."""
-    which = os.environ.get("YDS_BENCH_SHAPES", "cfg2,cfg3,cfg5").split(",")
+    which = os.environ.get("YDS_BENCH_SHAPES", "cfg2,cfg3,cfg5,cfg4s1").split(",")
     for name in which:
+        if name == "cfg4s1":         # BASELINE configs[3]: cfg3 on every rank, stream seed = rank; seed 0 is bench_shape_cfg3, this is rank 1's stream
+            _save("bench_shape_cfg4_seed1", **run_reference_stream(ns, "cfg3", 16, seed=1))
+            continue
         arrays = run_reference_stream(ns, name, 32)
         _save(f"bench_shape_{name}", **arrays)
 
 
-ALL = dict(bench_shape=gen_bench_shape, options=gen_track_options, tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
+def action_scene(n_frames=40):
+    """The scripted int32 tracker rows the action fixture is recorded on (shared with tests/test_host_logic.py)."""
+    rng = np.random.RandomState(0)
+    pos = rng.randint(0, 500, (6, 2)).astype(float)
+    vel = rng.randint(-6, 7, (6, 2)).astype(float)
+    frames = []
+    for t in range(n_frames):
+        pos += vel
+        if t % 7 == 0:
+            vel = rng.randint(-6, 7, (6, 2)).astype(float)
+        vis = [i for i in range(6) if rng.rand() > 0.25]
+        frames.append(np.array([[pos[i, 0], pos[i, 1], pos[i, 0] + 20, pos[i, 1] + 40, i + 1, (i % 2) * 2] for i in vis], np.int32).reshape(-1, 6))
+    return frames
+
+
+def gen_action(ns):
+    """action/ (SURVEY 8f row 2): ActionIdentify.update over 40 frames of scripted tracker rows with a stepped clock (the
+    module reads time.time() in Orbit.update: 40 ms per call here and in the test), including the speed-based FastCrossing."""
+    import json
+    import time
+    import action.action_Identify as rai
+    import action.actions as ra
+    assert ra.__file__.startswith(ref_harness.REF_ROOT)
+    tick = [1000.0]
+
+    def fake_time():
+        tick[0] += 0.04
+        return tick[0]
+    real = time.time
+    time.time = fake_time
+    try:
+        acts = [ra.TakeOff(0, (1, 2)), ra.Landing(0, (1, 2)), ra.Glide(0, (2, 4)), ra.FastCrossing(2, 0.05), ra.BreakInto(0, 2), ra.BreakInto(2, 1)]
+        A = rai.ActionIdentify(acts, max_age=3, max_size=4)
+        out = []
+        for det in action_scene():
+            out.append([[int(a), int(b), str(c)] for a, b, c in A.update(det)])
+        none_case = A.update(None)
+    finally:
+        time.time = real
+    with open(os.path.join(GOLD, "action_trace.json"), "w") as f:
+        json.dump(dict(frames=out, none_returns_none=none_case is None), f)
+    print("    action events:", sum(len(o) for o in out))
+
+
+ALL = dict(action=gen_action, bench_shape=gen_bench_shape, options=gen_track_options, tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
            nms=gen_nms, plumbing=gen_detect_plumbing, reid=gen_reid, kalman=gen_kalman,
            traces=gen_track_traces)
 

@@ -59,6 +59,7 @@ def install_shims():
         from .resize import resize_bilinear_u8
         cv2 = types.ModuleType("cv2")
         cv2.INTER_LINEAR = 1
+        cv2.VideoWriter_fourcc = lambda *c: "".join(c)          # a default argument of VideoDetector.__init__ (video_detect.py:49)
         cv2.COLOR_RGB2BGR = 4
         cv2.COLOR_BGR2RGB = 4
         cv2.FONT_HERSHEY_SIMPLEX = 0

@@ -45,7 +45,12 @@ def test_rank_beyond_device_count_fails_loudly():
     n = _lib.load().yds_device_count()
     code = ("import sys; sys.path.insert(0, %r)\nfrom yolo_deepsort_amd import _lib\n"
             "try:\n    _lib.init()\nexcept _lib.YdsError as e:\n    print('ERR', e)\nelse:\n    print('BOUND', _lib.current_device())\n" % ROOT)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LOCAL_RANK=str(n)), capture_output=True, text=True, timeout=300)
+    env = {k: v for k, v in os.environ.items() if k not in _lib.VISIBILITY_MASKS and k != "YDS_DEVICE"}
+    if len(env) != len(os.environ) and n == 1:
+        # the box itself masks its devices down to one: then LOCAL_RANK is not an ordinal (see the next-but-one test) and
+        # clearing the mask may expose more devices than the count above - ask for a device far outside either way
+        n = 64
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, LOCAL_RANK=str(n)), capture_output=True, text=True, timeout=300)
     assert "ERR" in out.stdout and "outside" in out.stdout, out.stdout + out.stderr
 
 
@@ -59,17 +64,93 @@ def test_two_ranks_use_two_gpus():
     assert line["n_gpus"] == 2 and len(set(line["config"]["rank_pci_bus_ids"])) == 2, line
 
 
-def test_two_rank_bench_path_on_one_gpu():
-    """The N > 1 code path end to end on the 1-GPU box: two processes under torch.distributed.run, one stream per rank
-    (seeds 0 and 1), barriers + max-over-ranks timing + gathered device ids - with both ranks bound to GPU 0 and gloo for
-    the rendezvous (RCCL refuses two ranks on one device; the real run uses nccl and one GPU per rank)."""
-    env = dict(os.environ, YDS_DEVICE="0", YDS_DIST_BACKEND="gloo")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
-                          "--cpu-frames", "0", "--no-extras", "--no-roofline"], capture_output=True, text=True, timeout=1500, env=env)
+def _bench(tmp, extra, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + extra + ["--cpu-frames", "0", "--no-extras", "--no-roofline", "--latency-steps", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env or os.environ)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, out.stdout[-500:] + out.stderr[-1500:]          # rank 0 prints ONE line
-    line = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_two_rank_bench_path_on_one_gpu(tmp_path):
+    """The N > 1 code path end to end on the 1-GPU box with BASELINE configs[3] (cfg4 = yolov4 + DeepSORT, one stream per rank,
+    seeds = rank): two processes under torch.distributed.run, barriers + max-over-ranks timing + the exchange step (all-gather
+    of every stream's result rows) - with both ranks bound to GPU 0 and gloo as transport (RCCL refuses two ranks on one
+    device; the real run uses RCCL and one GPU per rank).  The rows rank 0 gathered must equal two single-rank runs of
+    seeds 0 and 1 bit for bit."""
+    import numpy as np
+    env = dict(os.environ, YDS_DEVICE="0", YDS_DIST_BACKEND="gloo")
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29577"]
+    both = str(tmp_path / "both.npz")
+    line = _bench(tmp_path, ["--gpus", "2", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--batch", "4", "--dump-rows", both], env, launcher)
     assert line["n_gpus"] == 2 and line["config"]["streams"] == 2 and line["scaling"] == "weak"
     assert line["config"]["rank_devices"] == [0, 0] and line["value"] > 0
-    assert line["config"]["tracker_rows_out"] > 0                                                   # both streams produced rows
+    assert "one per GPU" in line["config"]["workload"] and "gloo" in line["exchange"]
+    g = np.load(both)
+    total = 0
+    for seed in (0, 1):
+        one = str(tmp_path / f"one{seed}.npz")
+        _bench(tmp_path, ["--gpus", "1", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--batch", "4", "--seed-base", str(seed), "--dump-rows", one])
+        h = np.load(one)
+        keys = sorted(k for k in g.files if k.startswith(f"s{seed}_"))
+        assert keys and sorted(h.files) == sorted(k.replace(f"s{seed}_", "s0_") for k in keys)
+        for k in keys:
+            assert np.array_equal(g[k], h[k.replace(f"s{seed}_", "s0_")]), (seed, k)
+            total += int((g[k][:, 4] >= 0).sum())
+    assert total == line["config"]["tracker_rows_out"] and total > 0                            # rank 0 holds BOTH streams' rows
+
+
+def test_rccl_comm_world_of_one():
+    """yds_comm_* on RCCL itself (ncclCommInitRank / ncclAllGather / ncclAllReduce) - a world of one rank is all a 1-GPU box
+    can form; the collectives must round-trip the exchange block and the reductions."""
+    import ctypes as C
+    import numpy as np
+    from yolo_deepsort_amd import dist
+    _lib.init()
+    lib = _lib.load()
+    assert lib.yds_comm_rccl_version() > 0
+    ident = (C.c_char * 128)()
+    _lib.check(lib.yds_comm_unique_id(ident))
+    comm = _lib.check_ptr(lib.yds_comm_create(ident, 1, 0))
+    try:
+        assert lib.yds_comm_world(comm) == 1 and lib.yds_comm_rank(comm) == 0
+        outs = [np.arange(12, dtype=np.int32).reshape(2, 6), None, np.zeros((0, 6), np.int32), np.full((256, 6), 7, np.int32)]
+        blk = dist.pack_rows(outs)
+        back = np.zeros((1,) + blk.shape, np.int32)
+        _lib.check(lib.yds_comm_allgather(comm, _lib.ptr(blk), blk.nbytes, _lib.ptr(back)))
+        got = dist.unpack_rows(back[0])
+        assert got[1] is None and all(np.array_equal(a, b) for a, b in zip([got[0], got[2], got[3]], [outs[0], outs[2], outs[3]]))
+        # the C-side packer from the pipeline's own output layout (out6 [batch, cap, 6] + counts)
+        cap = 300
+        out6 = np.zeros((3, cap, 6), np.int32)
+        out6[0, :2] = outs[0]
+        counts = np.array([2, -1, 0], np.int32)
+        allb = np.zeros((1, 3, dist.BLOCK), np.int32)
+        _lib.check(lib.yds_comm_allgather_rows(comm, _lib.ptr(out6), cap, _lib.ptr(counts), 3, _lib.ptr(allb)))
+        rows = dist.unpack_rows(allb[0])
+        assert np.array_equal(rows[0], outs[0]) and rows[1] is None and rows[2].shape == (0, 6)
+        v = (C.c_double * 2)(3.5, -1.0)
+        _lib.check(lib.yds_comm_allreduce_f64(comm, v, 2, 1))
+        assert list(v) == [3.5, -1.0]
+        _lib.check(lib.yds_comm_allreduce_f64(comm, v, 2, 0))
+        assert list(v) == [3.5, -1.0]
+        _lib.check(lib.yds_comm_barrier(comm))
+        # device-side variant
+        buf = _lib.DeviceBuffer.from_array(blk)
+        dst = _lib.DeviceBuffer(blk.nbytes)
+        _lib.check(lib.yds_comm_allgather_dev(comm, buf.ptr, blk.nbytes, dst.ptr))
+        back2 = np.zeros_like(blk)
+        _lib.check(lib.yds_memcpy_d2h(_lib.ptr(back2), dst.ptr, blk.nbytes))
+        assert np.array_equal(back2, blk)
+        too_many = np.zeros((1, cap, 6), np.int32)
+        assert lib.yds_comm_allgather_rows(comm, _lib.ptr(too_many), cap, _lib.ptr(np.array([257], np.int32)), 1, _lib.ptr(allb)) != 0
+        assert "exceed" in _lib.last_error()
+    finally:
+        lib.yds_comm_destroy(comm)
+
+
+def test_masked_rank_takes_its_only_visible_device():
+    """A launcher that masks the devices per rank (HIP_VISIBLE_DEVICES = one GPU each) leaves LOCAL_RANK = 3 with ordinal 0."""
+    code = ("import sys; sys.path.insert(0, %r)\nfrom yolo_deepsort_amd import _lib\nprint('BOUND', _lib.init(), _lib.pci_bus_id())\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LOCAL_RANK="3", HIP_VISIBLE_DEVICES="0"), capture_output=True, text=True, timeout=300)
+    assert "BOUND 0" in out.stdout, out.stdout + out.stderr

@@ -163,7 +163,7 @@ sys.path.insert(0, %r)
 from yolo_deepsort_amd.dist import Ranks
 from yolo_deepsort_amd import synth
 r = Ranks("gloo")
-assert r.world == 2
+assert r.world == 2 and r.comm is None
 scene = synth.PersonScene(5, seed=r.stream_seed())
 ids, boxes = scene.boxes(0)
 r.barrier()
@@ -171,6 +171,11 @@ dt = r.max_over_ranks(1.0 + r.rank)            # slowest rank defines the job ti
 tot = r.sum_over_ranks(float(boxes[:, 0].sum()))
 frames = r.total_frames(10, 8)
 assert r.gather_objects(("r", r.rank)) == [("r", 0), ("r", 1)]
+import numpy as np
+mine = [np.full((r.rank + 1, 6), 10 * r.rank + 1, np.int32), None if r.rank else np.zeros((0, 6), np.int32)]
+streams = r.connect().gather_rows(mine)          # the exchange step: every rank ends up with both streams' rows
+assert len(streams) == 2 and streams[0][0].shape == (1, 6) and streams[1][0].shape == (2, 6)
+assert int(streams[1][0][0, 0]) == 11 and streams[0][1].shape == (0, 6) and streams[1][1] is None
 if r.rank == 0:
     other = synth.PersonScene(5, seed=1).boxes(0)[1]
     assert dt == 2.0 and frames == 160
@@ -279,3 +284,141 @@ def test_label_drawer_and_file_video_stream():
     assert len(got) == 5 and all(np.array_equal(g, fr[:, :, ::-1]) for g, fr in zip(got, frames))
     with pytest.raises(IOError):
         FileVideoStream("/nonexistent/video.mp4")
+
+
+def test_reference_import_paths_resolve_without_a_gpu():
+    """Every import the reference demo and deep_sort/deep_sort.py:5-9 make resolves to this package (no device touched)."""
+    import importlib
+    want = {
+        "yolo3.models": ["Darknet"], "yolo3.detect.video_detect": ["VideoDetector"], "yolo3.detect.img_detect": ["ImageDetector"],
+        "yolo3.utils.model_build": ["soft_non_max_suppression", "xywh2p1p2", "p1p2Toxywh", "resize_boxes", "bbox_iou"],
+        "yolo3.utils.parse_config": ["parse_model_config"], "yolo3.utils.helper": ["load_classes"], "yolo3.utils.label_draw": ["LabelDrawer"],
+        "deep_sort": ["DeepSort", "build_tracker"], "deep_sort.deep_sort": ["DeepSort"], "deep_sort.deep.feature_extractor": ["Extractor"],
+        "deep_sort.sort.detection": ["Detection"], "deep_sort.sort.kalman_filter": ["KalmanFilter", "chi2inv95"],
+        "deep_sort.sort.nn_matching": ["NearestNeighborDistanceMetric"], "deep_sort.sort.preprocessing": ["non_max_suppression"],
+        "deep_sort.sort.iou_matching": ["iou", "iou_cost"], "deep_sort.sort.track": ["Track", "TrackState"],
+        "deep_sort.sort.linear_assignment": ["min_cost_matching", "matching_cascade", "gate_cost_matrix", "INFTY_COST"],
+        "deep_sort.sort.tracker": ["Tracker"], "action.action_Identify": ["ActionIdentify"],
+        "action.actions": ["TakeOff", "Landing", "Glide", "FastCrossing", "BreakInto"],
+    }
+    for mod, names in want.items():
+        m = importlib.import_module(mod)
+        assert m.__file__.startswith(ROOT), mod
+        for n in names:
+            assert hasattr(m, n), (mod, n)
+    # host-only helpers behave like the reference's definitions
+    from yolo3.utils.model_build import bbox_iou, resize_boxes, xywh2p1p2
+    b = np.array([[10., 20., 4., 6.]], np.float32)
+    assert np.array_equal(xywh2p1p2(b), np.array([[8., 17., 12., 23.]], np.float32))
+    np.testing.assert_allclose(resize_boxes(np.array([[304., 304., 608., 608.]], np.float32), (608, 608), (1080, 1920)), [[960., 540., 1920., 1080.]])
+    np.testing.assert_allclose(bbox_iou(np.array([[0., 0., 9., 9.]]), np.array([[5., 5., 14., 14.]])), [25. / 175.])
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not has_reference(), reason="reference tree not present")
+def test_public_signatures_match_the_reference():
+    """Constructor / method parameter names (and defaults) of the drop-in classes vs the reference's, read with inspect from the
+    reference sources imported under the oracle's shims."""
+    code = r'''
+import inspect, sys
+sys.path.insert(0, %r)
+from oracle import ref_harness
+ref_harness.install_shims()
+import importlib
+def sig(f):
+    return [(p.name, p.default if p.default is not inspect._empty else "<req>") for p in inspect.signature(f).parameters.values()]
+mine = {}
+import yolo3.detect.video_detect as a, yolo3.detect.img_detect as b, deep_sort as c, yolo3.models as d, deep_sort.sort.nn_matching as e, deep_sort.sort.tracker as f
+import deep_sort.sort.kalman_filter as k, deep_sort.sort.linear_assignment as la, yolo3.utils.model_build as mb, deep_sort.sort.preprocessing as pp
+assert a.__file__.startswith(%r)
+def collect():
+    import yolo3.detect.video_detect as a, yolo3.detect.img_detect as b, deep_sort as c, yolo3.models as d, deep_sort.sort.nn_matching as e, deep_sort.sort.tracker as f
+    import deep_sort.sort.kalman_filter as k, deep_sort.sort.linear_assignment as la, yolo3.utils.model_build as mb, deep_sort.sort.preprocessing as pp
+    import deep_sort.sort.detection as dt
+    return {
+        "VideoDetector.__init__": sig(a.VideoDetector.__init__), "VideoDetector.detect": sig(a.VideoDetector.detect),
+        "ImageDetector.__init__": sig(b.ImageDetector.__init__), "ImageDetector.detect": sig(b.ImageDetector.detect),
+        "DeepSort.__init__": sig(c.DeepSort.__init__), "DeepSort.update": sig(c.DeepSort.update),
+        "Darknet.__init__": sig(d.Darknet.__init__), "Darknet.load_darknet_weights": sig(d.Darknet.load_darknet_weights),
+        "Darknet.save_darknet_weights": sig(d.Darknet.save_darknet_weights),
+        "NNMetric.__init__": sig(e.NearestNeighborDistanceMetric.__init__), "NNMetric.distance": sig(e.NearestNeighborDistanceMetric.distance),
+        "NNMetric.partial_fit": sig(e.NearestNeighborDistanceMetric.partial_fit),
+        "Tracker.__init__": sig(f.Tracker.__init__), "Tracker.update": sig(f.Tracker.update), "Tracker.predict": sig(f.Tracker.predict),
+        "KalmanFilter.gating_distance": sig(k.KalmanFilter.gating_distance), "KalmanFilter.update": sig(k.KalmanFilter.update),
+        "min_cost_matching": sig(la.min_cost_matching), "gate_cost_matrix": sig(la.gate_cost_matrix),
+        "soft_non_max_suppression": sig(mb.soft_non_max_suppression), "bbox_iou": sig(mb.bbox_iou), "resize_boxes": sig(mb.resize_boxes),
+        "non_max_suppression": sig(pp.non_max_suppression), "Detection.__init__": sig(dt.Detection.__init__),
+    }
+mine = collect()
+for key in [m for m in sys.modules if m.split(".")[0] in ("yolo3", "deep_sort", "action")]:
+    del sys.modules[key]
+sys.path.insert(0, ref_harness.REF_ROOT)
+ref = collect()
+import yolo3.models as chk
+assert chk.__file__.startswith(ref_harness.REF_ROOT)
+extra_ok = {"VideoDetector.__init__": {"batch_frames"}, "DeepSort.__init__": {"metric"}, "Darknet.__init__": {"batch_max", "cfg_text"},
+            "Darknet.load_darknet_weights": {"blob"}}
+for name, r in ref.items():
+    m = mine[name]
+    if name == "VideoDetector.__init__":                      # (cv2.VideoWriter_fourcc('m','p','4','v') in the reference; the string here)
+        m = [(n, "mp4v" if n == "fourcc" else d) for n, d in m]
+        r = [(n, "mp4v" if n == "fourcc" else d) for n, d in r]
+    assert m[:len(r)] == r, (name, m, r)                      # same names, order and defaults; additions only at the end
+    assert {n for n, _ in m[len(r):]} <= extra_ok.get(name, set()), (name, m[len(r):])
+print("OK", len(ref))
+''' % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_checkpoint_reader_refuses_out_of_bounds_tensor_geometry():
+    """A pickle whose tensor geometry points outside its storage must be refused (ADVICE r2: as_strided on unchecked numbers)."""
+    import pickle
+    import zipfile
+
+    # write a checkpoint with torch, then corrupt the geometry through the reader's own objects
+    import torch
+    with tempfile.NamedTemporaryFile(suffix=".t7", delete=False) as f:
+        pass
+    try:
+        torch.save({"net_dict": {"w": torch.arange(12, dtype=torch.float32).reshape(3, 4)}}, f.name)
+        storages = {}
+        with zipfile.ZipFile(f.name) as z:
+            pkl = [n for n in z.namelist() if n.endswith("data.pkl")][0]
+            with z.open(pkl) as fh:
+                obj = loaders._make_unpickler(fh, storages).load()
+            for key, st in storages.items():
+                st.data = np.frombuffer(z.read(pkl[:-len("data.pkl")] + "data/" + key), dtype=st.dtype, count=st.numel)
+        t = obj["net_dict"]["w"]
+        assert np.array_equal(t.numpy(), np.arange(12, dtype=np.float32).reshape(3, 4))
+        for bad in (dict(offset=1), dict(offset=-1), dict(size=(3, 5)), dict(stride=(8, 1)), dict(stride=(-4, 1)), dict(size=(3,))):
+            u = loaders._LazyTensor(t.storage, bad.get("offset", t.offset), bad.get("size", t.size), bad.get("stride", t.stride))
+            with pytest.raises(ValueError):
+                u.numpy()
+        assert loaders._LazyTensor(t.storage, 0, (0, 4), (4, 1)).numpy().shape == (0, 4)       # empty tensors address nothing
+    finally:
+        os.unlink(f.name)
+
+
+def test_action_module_matches_committed_reference_fixture(monkeypatch):
+    """action/ (SURVEY 8f row 2) against the trace oracle/gen_golden.py recorded from the reference (40 frames of scripted
+    tracker rows, stepped clock) - runs without /root/reference, i.e. also on the GPU box."""
+    import json
+    import time
+    from conftest import GOLD
+    from oracle.gen_golden import action_scene
+    from yolo_deepsort_amd import action as mine
+    want = json.load(open(os.path.join(GOLD, "action_trace.json")))
+    tick = [1000.0]
+
+    def fake_time():
+        tick[0] += 0.04
+        return tick[0]
+    monkeypatch.setattr(time, "time", fake_time)
+    acts = [mine.TakeOff(0, (1, 2)), mine.Landing(0, (1, 2)), mine.Glide(0, (2, 4)), mine.FastCrossing(2, 0.05), mine.BreakInto(0, 2),
+            mine.BreakInto(2, 1)]
+    B = mine.ActionIdentify(acts, max_age=3, max_size=4)
+    for t, det in enumerate(action_scene()):
+        got = [[int(a), int(b), str(c)] for a, b, c in B.update(det)]
+        assert got == want["frames"][t], t
+    assert (B.update(None) is None) == want["none_returns_none"]

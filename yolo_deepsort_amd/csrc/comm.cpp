@@ -1,0 +1,190 @@
+// Multi-GPU exchange step of the stream-sharded run: one process per GPU, one video stream per rank, and ONE
+// collective per frame batch - an all-gather of every rank's fixed-size result block {int32 count; int32 rows[256][6]} per
+// frame so that rank 0 can emit all streams' tracker rows - plus small all-reduces (counters, the max-over-ranks time)
+// and a barrier.  RCCL directly (ncclCommInitRank from an id the launcher distributes), on this library's own stream on
+// the bound device; no torch types, no torch.distributed on the data path.
+//
+// librccl is opened lazily with dlopen (RTLD_LOCAL) and only when a communicator is created: single-GPU users never load
+// it, and the copy a Python process may already have mapped (torch ships one) is never mixed with another by symbol name.
+//
+// The reference has no distributed code; the per-stream contract is DeepSort.clone() (deep_sort/deep_sort.py:41-44).
+#include "common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <vector>
+
+#include "ydsort.h"
+
+namespace yds {
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    if (r.h) return r;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *n : names) {
+        r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.h) break;
+    }
+    if (!r.h) fail("comm: librccl not found (%s); multi-GPU runs need RCCL", dlerror());
+    auto sym = [&](const char *n) {
+        void *p = dlsym(r.h, n);
+        if (!p) fail("comm: librccl has no symbol %s", n);
+        return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+    return r;
+}
+
+#define YDS_NCCL(call)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (call);                                                                   \
+        if (r_ != ncclSuccess) ::yds::fail("RCCL: %s failed: %s", #call, ::yds::rccl().GetErrorString(r_)); \
+    } while (0)
+
+}  // namespace
+}  // namespace yds
+
+struct yds_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    hipStream_t stream = nullptr;
+    yds::DevBuf<char> send, recv;         // staging for host-side payloads
+    char *pin = nullptr;                  // pinned bounce buffer
+    size_t pin_bytes = 0;
+
+    void ensure(size_t send_bytes, size_t recv_bytes) {
+        if (send.n < send_bytes) send.alloc(send_bytes * 2);
+        if (recv.n < recv_bytes) recv.alloc(recv_bytes * 2);
+        if (pin_bytes < recv_bytes + send_bytes) {
+            if (pin) (void)hipHostFree(pin);
+            pin_bytes = (recv_bytes + send_bytes) * 2;
+            YDS_HIP(hipHostMalloc((void **)&pin, pin_bytes));
+        }
+    }
+};
+
+extern "C" {
+
+int yds_comm_unique_id(void *id128_out) {
+    YDS_API_BEGIN
+    static_assert(sizeof(ncclUniqueId) == YDS_COMM_ID_BYTES, "RCCL unique id size");
+    ncclUniqueId id;
+    YDS_NCCL(yds::rccl().GetUniqueId(&id));
+    memcpy(id128_out, &id, sizeof id);
+    YDS_API_END
+}
+
+yds_comm *yds_comm_create(const void *id128, int world, int rank) {
+    YDS_API_BEGIN
+    if (yds::bound_device() < 0) yds::fail("comm: yds_init has not bound a device");
+    if (world < 1 || rank < 0 || rank >= world) yds::fail("comm: rank %d outside world %d", rank, world);
+    yds_comm *c = new yds_comm;
+    c->world = world;
+    c->rank = rank;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    c->stream = yds::make_stream(true);
+    YDS_NCCL(yds::rccl().CommInitRank(&c->comm, world, id, rank));      // collective: every rank of the job calls it
+    return c;
+    YDS_API_END_PTR
+}
+
+void yds_comm_destroy(yds_comm *c) {
+    if (!c) return;
+    yds::bind_thread();
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)yds::rccl().CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->pin) (void)hipHostFree(c->pin);
+    delete c;
+}
+
+int yds_comm_world(const yds_comm *c) { return c ? c->world : 1; }
+int yds_comm_rank(const yds_comm *c) { return c ? c->rank : 0; }
+
+int yds_comm_rccl_version(void) {
+    YDS_API_BEGIN
+    int v = 0;
+    YDS_NCCL(yds::rccl().GetVersion(&v));
+    return v;
+    }
+    catch (const std::exception &e) { yds::set_error(e.what()); return -1; }
+}
+
+int yds_comm_allgather_dev(yds_comm *c, const void *send_dev, size_t bytes, void *recv_dev) {
+    YDS_API_BEGIN
+    YDS_NCCL(yds::rccl().AllGather(send_dev, recv_dev, bytes, ncclChar, c->comm, c->stream));
+    YDS_HIP(hipStreamSynchronize(c->stream));
+    YDS_API_END
+}
+
+int yds_comm_allgather(yds_comm *c, const void *send_host, size_t bytes, void *recv_host) {
+    YDS_API_BEGIN
+    const size_t total = bytes * (size_t)c->world;
+    c->ensure(bytes, total);
+    memcpy(c->pin, send_host, bytes);
+    YDS_HIP(hipMemcpyAsync(c->send.p, c->pin, bytes, hipMemcpyHostToDevice, c->stream));
+    YDS_NCCL(yds::rccl().AllGather(c->send.p, c->recv.p, bytes, ncclChar, c->comm, c->stream));
+    YDS_HIP(hipMemcpyAsync(c->pin + bytes, c->recv.p, total, hipMemcpyDeviceToHost, c->stream));
+    YDS_HIP(hipStreamSynchronize(c->stream));
+    memcpy(recv_host, c->pin + bytes, total);
+    YDS_API_END
+}
+
+/* the result block of the exchange step: per frame {int32 count; int32 rows[YDS_COMM_MAX_ROWS][6]} */
+int yds_comm_allgather_rows(yds_comm *c, const int32_t *out6_host, int cap, const int32_t *counts_host, int batch, int32_t *all_host) {
+    YDS_API_BEGIN
+    constexpr int BLK = 1 + YDS_COMM_MAX_ROWS * 6;
+    std::vector<int32_t> blk((size_t)batch * BLK, 0);
+    for (int b = 0; b < batch; ++b) {
+        const int n = counts_host[b];
+        if (n > YDS_COMM_MAX_ROWS) yds::fail("comm: %d tracker rows in one frame exceed the exchange block (%d)", n, YDS_COMM_MAX_ROWS);
+        blk[(size_t)b * BLK] = n;                                        // -1 = the detector returned None for this frame
+        if (n > 0) memcpy(&blk[(size_t)b * BLK + 1], out6_host + (size_t)b * cap * 6, (size_t)n * 6 * sizeof(int32_t));
+    }
+    return yds_comm_allgather(c, blk.data(), blk.size() * sizeof(int32_t), all_host);
+    }
+    catch (const std::exception &e) { yds::set_error(e.what()); return -1; }
+}
+
+int yds_comm_allreduce_f64(yds_comm *c, double *vals_host, int n, int op) {
+    YDS_API_BEGIN
+    if (op != 0 && op != 1) yds::fail("comm: op must be 0 (sum) or 1 (max)");
+    const size_t bytes = (size_t)n * sizeof(double);
+    c->ensure(bytes, bytes);
+    memcpy(c->pin, vals_host, bytes);
+    YDS_HIP(hipMemcpyAsync(c->send.p, c->pin, bytes, hipMemcpyHostToDevice, c->stream));
+    YDS_NCCL(yds::rccl().AllReduce(c->send.p, c->recv.p, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
+    YDS_HIP(hipMemcpyAsync(c->pin + bytes, c->recv.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    YDS_HIP(hipStreamSynchronize(c->stream));
+    memcpy(vals_host, c->pin + bytes, bytes);
+    YDS_API_END
+}
+
+int yds_comm_barrier(yds_comm *c) {
+    double one = 1.0;
+    return yds_comm_allreduce_f64(c, &one, 1, 0);
+}
+
+}  // extern "C"

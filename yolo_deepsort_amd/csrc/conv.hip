@@ -209,6 +209,11 @@ double conv_flops(const ConvArgs &a) {
     return 2.0 * (double)a.y.pixels() * a.y.c * a.ksize * a.ksize * a.x.c;
 }
 
+double conv_bytes_io(const View &v) { return (double)v.pixels() * v.c * 4.0; }      // fp32 and H16 tensors both hold 4 bytes per channel
+double conv_bytes(const ConvArgs &a) {
+    return conv_bytes_io(a.x) + conv_bytes_io(a.y) + (a.res.p ? conv_bytes_io(a.res) : 0.0) + (double)a.y.c * a.kpad * 4.0;
+}
+
 const char *conv_variant_name(int v) {
     static const char *names[kF32Variants] = {"conv_igemm_f32<128,128,2,2,32>", "conv_igemm_f32<128,64,2,2,32>", "conv_igemm_f32<64,64,2,2,32>",
                                                "conv_igemm_f32<128,32,4,1,32>", "conv_igemm_f32<128,128,2,2,16>", "conv_igemm_f32<128,64,2,2,16>",
@@ -353,9 +358,10 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
     if (const char *f = getenv("YDS_CONV_FORCE")) {      // tuning aid: pin a variant id where it is applicable
         int v = atoi(f);
         const bool f16v = v >= kF32Variants && v != kDirectVariant;
-        const bool presplit = f16v && (f16_variant_is_dma(v - kF32Variants) || f16_variant_is_win(v - kF32Variants));
+        const bool presplit = f16v && (f16_variant_is_dma(v - kF32Variants) || f16_variant_is_win(v - kF32Variants) || f16_variant_is_win2(v - kF32Variants));
         if (v == kDirectVariant && !conv_direct_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (f16v && f16_variant_is_win(v - kF32Variants) && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
+        if (f16v && f16_variant_is_win2(v - kF32Variants) && !conv_win2_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (!(presplit && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
     const std::string key = tune_key(a);
@@ -385,7 +391,8 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
         const int fv = v - kF32Variants;                // f16x3 variant index (meaningful for kF32Variants <= v < kDirectVariant)
         const bool f16v = v >= kF32Variants && v != kDirectVariant;
-        if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv)) && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // need a pre-split input
+        if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv) || f16_variant_is_win2(fv)) && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // need a pre-split input
+        if (f16v && f16_variant_is_win2(fv) && (!conv_win2_applicable(make_conv_args(a)) || a.y.c < 128)) continue;
         if (f16v && f16_variant_is_win(fv) && !conv_win_applicable(make_conv_args(a))) continue;
         if (f16v && f16_variant_is_win(fv) && fv > 8 && a.y.c > 64) continue;          // 64-wide window tiles are for 64-filter layers
         cand.push_back(v);

@@ -249,9 +249,13 @@ bool conv_pool_applicable(const ConvKernelArgs &k);
 void launch_conv_pool(const ConvKernelArgs &k, hipStream_t s);
 
 // split-fp16 path (conv_f16x3.hip)
-constexpr int kF16Variants = 13;           // 0-3 register-staged tiles, 4-7 and 11-12 LDS-DMA ring, 8-10 window-resident 3x3 (pre-split inputs only)
+constexpr int kF16Variants = 14;           // 0-3 register-staged tiles, 4-7 and 11-12 LDS-DMA ring, 8-10 window-resident 3x3, 13 window-resident with two workgroups per CU (pre-split inputs only)
 inline bool f16_variant_is_dma(int v) { return (v >= 4 && v <= 7) || v == 11 || v == 12; }
 inline bool f16_variant_is_win(int v) { return v >= 8 && v <= 10; }
+inline bool f16_variant_is_win2(int v) { return v == 13; }
+// two-workgroup window kernel (conv_win2.hip): 128x128 tiles, 4 waves, 16-channel K steps
+bool conv_win2_applicable(const ConvKernelArgs &k);
+void launch_conv_win2(ConvKernelArgs k, hipStream_t s);
 // window-resident 3x3 stride-1 kernel (conv_win.hip)
 bool conv_win_applicable(const ConvKernelArgs &k);
 void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s);   // shape 0: 256x128 (4x2 waves), 1: 256x64 (8x1), 2: 256x64 (4x2)

@@ -530,7 +530,7 @@ const char *conv_f16x3_variant_name(int v) {
                                               "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,2x2,2>", "conv_igemm_f16x3_dma<256,128,4x2,3>",
                                               "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>", "conv3x3_f16x3_win<256,128,4x2>",
                                               "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>",
-                                              "conv_igemm_f16x3_dma<128,64,2x2,2>", "conv_igemm_f16x3_dma<64,128,2x2,2>"};
+                                              "conv_igemm_f16x3_dma<128,64,2x2,2>", "conv_igemm_f16x3_dma<64,128,2x2,2>", "conv3x3_f16x3_win2<128,128,2x2>"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
 }
 
@@ -550,6 +550,7 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s) {
         // small LDS-DMA tiles (48 KB of LDS: three workgroups per CU): layers whose 128x128 tile count leaves a long tail -
         // the 1x1 layers at 76^2 / 38^2 / 19^2 run 1.4 rounds of 128x128 tiles on 512 slots, i.e. pay for 2
         case 11: launch_cfg_dma<128, 64, 2, 2, 2>(k, s); break;
+        case 13: launch_conv_win2(k, s); break;
         default: launch_cfg_dma<64, 128, 2, 2, 2>(k, s); break;
     }
 }

@@ -306,7 +306,8 @@ void Darknet::set_batch_max(int b) {
 }
 
 Darknet::~Darknet() {
-    if (ev0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); }
+    for (const ConvTimeRec &r : conv_pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -475,15 +476,18 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
             ConvArgs a = conv_args(i, batch);
             if (i == 0 && stem_fused(batch)) continue;              // computed inside layer 1's launch
             if (i == block1_at && block1_fused(batch)) continue;    // computed inside the next layer's launch
-            if (time_convs) YDS_HIP(hipEventRecord(ev0, stream));
+            ConvTimeRec rec;
+            if (time_convs) { rec.e0 = timing_event(); rec.e1 = timing_event(); YDS_HIP(hipEventRecord(rec.e0, stream)); }
             int variant;
+            double extra_flops = 0, extra_bytes = 0;
             if (i == 1 && stem_fused(batch)) {
                 ConvArgs a0 = conv_args(0, batch);
                 ConvKernelArgs k0 = make_conv_args(a0), k1 = make_conv_args(a);
                 k1.w = reinterpret_cast<const float *>(a.w16);
                 launch_conv_stem2(k0, k1, stream);
                 variant = kDirectVariant;                           // accounted with the direct first-layer kernel
-                if (time_convs) conv_flops_acc[variant] += conv_flops(a0);
+                extra_flops = conv_flops(a0);
+                extra_bytes = conv_bytes(a0) - conv_bytes_io(a0.y) - conv_bytes_io(a.x);     // the intermediate tensor never reaches HBM
             } else if (i == block1_at + 1 && block1_at >= 0 && block1_fused(batch)) {
                 ConvArgs a2 = conv_args(block1_at, batch);
                 ConvKernelArgs k2 = make_conv_args(a2), k3 = make_conv_args(a);
@@ -491,18 +495,22 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
                 k3.w = reinterpret_cast<const float *>(a.w16);
                 launch_conv_block1(k2, k3, stream);
                 variant = kF32Variants + 8;                         // accounted with the window-resident 3x3 kernel
-                if (time_convs) conv_flops_acc[variant] += conv_flops(a2);
+                extra_flops = conv_flops(a2);
+                // the block input is read once (it is also the residual), the 32-channel intermediate never reaches HBM
+                extra_bytes = conv_bytes(a2) - conv_bytes_io(a2.y) - conv_bytes_io(a.x) - (a.res.p ? conv_bytes_io(a.res) : 0.0);
             } else {
                 variant = launch_conv(a, stream, l.variant);
             }
             if (time_convs) {
-                YDS_HIP(hipEventRecord(ev1, stream));
-                YDS_HIP(hipEventSynchronize(ev1));
-                float ms = 0;
-                YDS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-                conv_us[variant] += ms * 1e3;
-                conv_launches[variant]++;
-                conv_flops_acc[variant] += conv_flops(a);
+                // no host synchronisation here: the pair is resolved when the counters are read, so the pass runs exactly as it
+                // does untimed (other streams live, the stream fed a pass ahead)
+                YDS_HIP(hipEventRecord(rec.e1, stream));
+                rec.variant = variant;
+                rec.flops = conv_flops(a) + extra_flops;
+                rec.bytes = conv_bytes(a) + extra_bytes;
+                const double peak = conv_math() == MATH_F32 ? 157.3e12 : (a.terms == 1 ? 2500e12 : 2500e12 / 3);
+                rec.attain_us = std::max(rec.flops / peak, rec.bytes / 6.29e12) * 1e6;
+                conv_pending.push_back(rec);
             }
         } else if (l.type == "maxpool") {
             // SPP (yolov4: 5 / 9 / 13, stride 1, all on one tensor): a k x k max with -inf padding is a 5 x 5 max of the
@@ -696,8 +704,33 @@ int64_t Darknet::flops_per_image() const {
 }
 
 void Darknet::enable_conv_timing(bool on) {
-    if (on && !ev0) { YDS_HIP(hipEventCreate(&ev0)); YDS_HIP(hipEventCreate(&ev1)); }
+    if (!on) resolve_conv_timing();
     time_convs = on;
+}
+
+hipEvent_t Darknet::timing_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    YDS_HIP(hipEventCreate(&e));
+    return e;
+}
+
+// Waits for the stream, turns every recorded (start, stop) pair into per-variant totals and recycles the events.
+void Darknet::resolve_conv_timing() {
+    if (conv_pending.empty()) return;
+    YDS_HIP(hipStreamSynchronize(stream));
+    for (const ConvTimeRec &r : conv_pending) {
+        float ms = 0;
+        YDS_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        conv_us[r.variant] += ms * 1e3;
+        conv_launches[r.variant]++;
+        conv_flops_acc[r.variant] += r.flops;
+        conv_bytes_acc[r.variant] += r.bytes;
+        conv_attain_us[r.variant] += r.attain_us;
+        ev_pool.push_back(r.e0);
+        ev_pool.push_back(r.e1);
+    }
+    conv_pending.clear();
 }
 
 }  // namespace yds
@@ -782,20 +815,28 @@ int yds_darknet_set_injection(yds_net *n, int image, const float *rows, int cnt,
     n->d->set_injection(image, rows, cnt, logit);
     YDS_API_END
 }
-int yds_conv_timing(yds_net *n, int mode, double *total_us4, int64_t *launches4, double *flops4) {
+int yds_conv_timing_ex(yds_net *n, int mode, double *total_us, int64_t *launches, double *flops, double *bytes, double *attainable_us) {
     YDS_API_BEGIN
     Darknet *d = n->d;
+    if (mode == 2) d->enable_conv_timing(false);           // resolves the pending event pairs (one stream synchronisation)
+    else d->resolve_conv_timing();
     for (int v = 0; v < yds::kConvVariants; ++v) {
-        if (total_us4) total_us4[v] = d->conv_us[v];
-        if (launches4) launches4[v] = d->conv_launches[v];
-        if (flops4) flops4[v] = d->conv_flops_acc[v];
+        if (total_us) total_us[v] = d->conv_us[v];
+        if (launches) launches[v] = d->conv_launches[v];
+        if (flops) flops[v] = d->conv_flops_acc[v];
+        if (bytes) bytes[v] = d->conv_bytes_acc[v];
+        if (attainable_us) attainable_us[v] = d->conv_attain_us[v];
     }
     if (mode == 1) {
-        for (int v = 0; v < yds::kConvVariants; ++v) { d->conv_us[v] = 0; d->conv_launches[v] = 0; d->conv_flops_acc[v] = 0; }
+        for (int v = 0; v < yds::kConvVariants; ++v) {
+            d->conv_us[v] = 0; d->conv_launches[v] = 0; d->conv_flops_acc[v] = 0; d->conv_bytes_acc[v] = 0; d->conv_attain_us[v] = 0;
+        }
         d->enable_conv_timing(true);
     }
-    if (mode == 2) d->enable_conv_timing(false);
     YDS_API_END
+}
+int yds_conv_timing(yds_net *n, int mode, double *total_us4, int64_t *launches4, double *flops4) {
+    return yds_conv_timing_ex(n, mode, total_us4, launches4, flops4, nullptr, nullptr);
 }
 const char *yds_conv_variant_name(int v) { return yds::conv_variant_name(v); }
 int yds_conv_num_variants(void) { return yds::kConvVariants; }

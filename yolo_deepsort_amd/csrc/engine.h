@@ -101,10 +101,15 @@ public:
     int inject_max_rows = 0;
     int inject_set = -1;
     float inject_logit = 6.f;
-    // conv timing (HIP events on this stream)
+    // conv timing: a HIP event pair around every conv launch on this stream, resolved when the counters are read (no host
+    // synchronisation inside the pass)
+    struct ConvTimeRec { hipEvent_t e0 = nullptr, e1 = nullptr; int variant = 0; double flops = 0, bytes = 0, attain_us = 0; };
     bool time_convs = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double conv_us[kConvVariants] = {}, conv_flops_acc[kConvVariants] = {};
+    std::vector<ConvTimeRec> conv_pending;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t timing_event();
+    void resolve_conv_timing();
+    double conv_us[kConvVariants] = {}, conv_flops_acc[kConvVariants] = {}, conv_bytes_acc[kConvVariants] = {}, conv_attain_us[kConvVariants] = {};
     int64_t conv_launches[kConvVariants] = {};
 
 private:

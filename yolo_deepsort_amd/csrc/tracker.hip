@@ -183,6 +183,64 @@ __global__ void gating_kernel(const float *mean, const float *cov, const int *sl
     out[idx] = gate2(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64, xyah + d * 4);
 }
 
+// squared Mahalanobis distance on all four measurement dimensions (only_position=False, kalman_filter.py:236-254):
+// d S^-1 d^T with S^-1 by Gauss-Jordan on the 4x4 projected covariance (torch.inverse in the reference)
+__device__ __forceinline__ float gate4(const float *m, const float *P, const float *z) {
+    float S[4][4], I[4][4];
+    project4(m, P, S);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) I[i][j] = i == j ? 1.f : 0.f;
+    for (int k = 0; k < 4; ++k) {
+        int p = k;
+        float best = fabsf(S[k][k]);
+        for (int r = k + 1; r < 4; ++r)
+            if (fabsf(S[r][k]) > best) { best = fabsf(S[r][k]); p = r; }
+        if (p != k)
+            for (int j = 0; j < 4; ++j) { float a = S[k][j]; S[k][j] = S[p][j]; S[p][j] = a; float b = I[k][j]; I[k][j] = I[p][j]; I[p][j] = b; }
+        const float inv = 1.f / S[k][k];
+        for (int j = 0; j < 4; ++j) { S[k][j] *= inv; I[k][j] *= inv; }
+        for (int r = 0; r < 4; ++r) {
+            if (r == k) continue;
+            const float f = S[r][k];
+            for (int j = 0; j < 4; ++j) { S[r][j] -= f * S[k][j]; I[r][j] -= f * I[k][j]; }
+        }
+    }
+    float d[4], t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) d[i] = z[i] - m[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] = d[0] * I[0][j] + d[1] * I[1][j] + d[2] * I[2][j] + d[3] * I[3][j];
+    return t[0] * d[0] + t[1] * d[1] + t[2] * d[2] + t[3] * d[3];
+}
+__global__ void gating4_kernel(const float *mean, const float *cov, int T, const float *xyah, int D, float *out) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= T * D) return;
+    int t = idx / D, d = idx - t * D;
+    out[idx] = gate4(mean + (size_t)t * 8, cov + (size_t)t * 64, xyah + d * 4);
+}
+// KalmanFilter.initiate from (x, y, a, h) rows (kalman_filter.py:54-87) and KalmanFilter.project (:125-158), stand-alone
+__global__ void kf_initiate_xyah_kernel(const float *xyah, float *mean, float *cov, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float *z = xyah + (size_t)t * 4;
+    const float b[4] = {z[0] - z[2] * z[3] / 2.f, z[1] - z[3] / 2.f, z[2] * z[3], z[3]};
+    kf_initiate_body(mean + (size_t)t * 8, cov + (size_t)t * 64, b);
+    float *m = mean + (size_t)t * 8;
+    m[0] = z[0]; m[1] = z[1]; m[2] = z[2]; m[3] = z[3];        // the measurement itself, not a tlwh round trip
+}
+__global__ void kf_project_kernel(const float *mean, const float *cov, float *mean4, float *cov16, int n) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float S[4][4];
+    project4(mean + (size_t)t * 8, cov + (size_t)t * 64, S);
+    for (int i = 0; i < 4; ++i) {
+        mean4[(size_t)t * 4 + i] = mean[(size_t)t * 8 + i];
+        for (int j = 0; j < 4; ++j) cov16[(size_t)t * 16 + i * 4 + j] = S[i][j];
+    }
+}
+
 // ------------------------------------------------------------------------------------- appearance cost
 // cost[t][d] = min over the gallery rows of track t of 1 - <g/|g|, f/|f|>, then Mahalanobis gate and the
 // min_cost_matching clamp.  Gallery rows are normalised once when they are appended and detections once per frame
@@ -732,7 +790,8 @@ enum Meta {
     M_NUT,          // unmatched tracks (final)
     M_NUD,          // unmatched detections (final) = new tracks
     M_NOUT,         // output rows
-    M_COUNT = 16
+    M_MAXFEAT,      // largest gallery row count of any live track (sizes the nn_budget=None galleries)
+    M_COUNT = 20
 };
 
 struct TrkDev {
@@ -907,6 +966,16 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
     // ---- output selection (deep_sort.py:67-71): confirmed and time_since_update <= 1, in list order
     const int n_out = compact_ordered(alive, s_cnt, [&](int t) { return d.tab.state[t] == CONFIRMED && d.tab.tsu[t] <= 1; },
                                       [&](int t, int r) { d.out_slot[r] = d.tab.slot[t]; d.out_id[r] = d.tab.id[t]; d.out_payload[r] = d.tab.payload[t]; });
+    // ---- largest gallery of a live track: the host grows unbounded galleries by what is really held, not by frames seen
+    __shared__ int s_maxfeat;
+    if (tid == 0) s_maxfeat = 0;
+    __syncthreads();
+    {
+        int mf = 0;
+        for (int t = tid; t < alive; t += 256) mf = max(mf, d.tab.n_feat[t]);
+        if (mf) atomicMax(&s_maxfeat, mf);
+    }
+    __syncthreads();
     // ---- debug lists for the parity tests
     for (int k = tid; k < 2 * M; k += 256) d.res[d.res_matches + k] = d.matches[k];
     for (int q = tid; q < n_um_t; q += 256) d.res[d.res_um_t + q] = d.um_t[q];
@@ -914,6 +983,7 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
     if (tid == 0) {
         d.meta[M_T] = alive; d.meta[M_NEXT_ID] = next_id + Nn; d.meta[M_NFREE] = n_free - Nn + freed;
         d.meta[M_NM] = M; d.meta[M_NUT] = n_um_t; d.meta[M_NUD] = Nn; d.meta[M_NOUT] = n_out;
+        d.meta[M_MAXFEAT] = s_maxfeat;
         for (int k = 0; k < M_COUNT; ++k) d.res[k] = d.meta[k];
     }
 }
@@ -1015,6 +1085,12 @@ public:
     void grow_budget() {
         YDS_HIP(hipStreamSynchronize(stream));
         const int nb = budget * 2;
+        size_t free_b = 0, total_b = 0;
+        YDS_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t need = (size_t)capacity * nb * EMB * 4;
+        if (need > free_b)
+            fail("tracker: nn_budget=None galleries would need %zu MB for %d slots x %d rows (%zu MB free); use a finite nn_budget",
+                 need >> 20, capacity, nb, free_b >> 20);
         DevBuf<float> g((size_t)capacity * nb * EMB);
         YDS_HIP(hipMemcpy2D(g.p, (size_t)nb * EMB * 4, gallery.p, (size_t)budget * EMB * 4, (size_t)budget * EMB * 4, capacity, hipMemcpyDeviceToDevice));
         gallery = std::move(g);
@@ -1100,7 +1176,9 @@ public:
         int D_sum = 0;
         for (int b = 0; b < n_frames; ++b) D_sum += frames[b].D;
         if (T_host + D_sum > capacity) { int c = capacity; while (c < T_host + D_sum) c *= 2; grow(c); }
-        if (unbounded) while (max_rows_ub + n_frames + 1 > budget) grow_budget();
+        // (max_rows = the largest gallery any LIVE track held after the last synchronised frame, from the result header;
+        //  every frame of this call can add one row to it)
+        if (unbounded) while (max_rows + n_frames + 1 > budget) grow_budget();
         // ---- inputs of all frames in one pinned block, one upload
         std::vector<size_t> in_off(n_frames);
         size_t in_total = 0;
@@ -1164,8 +1242,8 @@ public:
             std::sort(last_um_t.begin(), last_um_t.end());
             last_um_d.assign(pd, pd + r[M_NUD]);
             T_host = r[M_T];
+            max_rows = r[M_MAXFEAT];
         }
-        max_rows_ub += n_frames;
     }
 
     int step(const float *tlwh_host, const float *feats, bool feats_on_device, const float *payload, int D, int32_t *out6, int cap) override {
@@ -1217,7 +1295,7 @@ public:
     int metric = METRIC_COSINE;
     int capacity = 0;
     int T_host = 0;                 // live tracks after the last synchronised frame
-    int max_rows_ub = 1;            // upper bound of any gallery's row count (unbounded mode: +1 per frame)
+    int max_rows = 1;               // largest gallery row count of a live track after the last synchronised frame
     template <class T> struct GrowBuf : DevBuf<T> {
         // ensure() that never shrinks and - unlike DevBuf::ensure - may only be called while nothing that uses the old buffer is
         // in flight; growth is rare (sizes follow the largest frame seen), so it simply drains the stream first
@@ -1325,6 +1403,14 @@ int yds_tracker_get_state(yds_trk *t, int32_t *ids, int32_t *state, int32_t *tsu
     }
     YDS_API_END
 }
+int yds_tracker_get_payload(yds_trk *t, float *payload, int cap) {
+    YDS_API_BEGIN
+    yds::Tracker *k = impl(t);
+    const int n = k->T_host;
+    if (n > cap) yds::fail("tracker: %d tracks exceed cap %d", n, cap);
+    if (n) YDS_HIP(hipMemcpy(payload, k->table.p + (size_t)8 * k->capacity, (size_t)n * 4, hipMemcpyDeviceToHost));
+    YDS_API_END
+}
 int yds_tracker_last_unmatched(yds_trk *t, int32_t *um_tracks, int cap_t, int *n_t, int32_t *um_dets, int cap_d, int *n_d) {
     YDS_API_BEGIN
     const auto &a = impl(t)->last_um_t, &b = impl(t)->last_um_d;
@@ -1419,6 +1505,45 @@ int yds_kalman_gating(const float *mean_host, const float *cov_host, int T, cons
     auto v = iota(T); sl.upload(v.data(), T, s);
     hipLaunchKernelGGL(gating_kernel, dim3((T * D + 255) / 256), dim3(256), 0, s, m.p, c.p, sl.p, T, z.p, D, o.p);
     YDS_HIP(hipMemcpyAsync(out, o.p, (size_t)T * D * 4, hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipStreamSynchronize(s));
+    YDS_API_END
+}
+int yds_kalman_gating_ex(const float *mean_host, const float *cov_host, int T, const float *xyah_host, int D, int only_position, float *out) {
+    if (only_position) return yds_kalman_gating(mean_host, cov_host, T, xyah_host, D, out);
+    YDS_API_BEGIN
+    using namespace yds;
+    if (T == 0 || D == 0) return 0;
+    hipStream_t s = g_scratch.stream();
+    DevBuf<float> m, c, z, o((size_t)T * D);
+    m.upload(mean_host, (size_t)T * 8, s); c.upload(cov_host, (size_t)T * 64, s); z.upload(xyah_host, (size_t)D * 4, s);
+    hipLaunchKernelGGL(gating4_kernel, dim3((T * D + 255) / 256), dim3(256), 0, s, m.p, c.p, T, z.p, D, o.p);
+    YDS_HIP(hipMemcpyAsync(out, o.p, (size_t)T * D * 4, hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipStreamSynchronize(s));
+    YDS_API_END
+}
+int yds_kalman_initiate(const float *xyah_host, int n, float *mean_host, float *cov_host) {
+    YDS_API_BEGIN
+    using namespace yds;
+    if (n == 0) return 0;
+    hipStream_t s = g_scratch.stream();
+    DevBuf<float> z, m((size_t)n * 8), c((size_t)n * 64);
+    z.upload(xyah_host, (size_t)n * 4, s);
+    hipLaunchKernelGGL(kf_initiate_xyah_kernel, dim3((n + 63) / 64), dim3(64), 0, s, z.p, m.p, c.p, n);
+    YDS_HIP(hipMemcpyAsync(mean_host, m.p, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipMemcpyAsync(cov_host, c.p, (size_t)n * 256, hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipStreamSynchronize(s));
+    YDS_API_END
+}
+int yds_kalman_project(const float *mean_host, const float *cov_host, int n, float *mean4_host, float *cov16_host) {
+    YDS_API_BEGIN
+    using namespace yds;
+    if (n == 0) return 0;
+    hipStream_t s = g_scratch.stream();
+    DevBuf<float> m, c, m4((size_t)n * 4), c16((size_t)n * 16);
+    m.upload(mean_host, (size_t)n * 8, s); c.upload(cov_host, (size_t)n * 64, s);
+    hipLaunchKernelGGL(kf_project_kernel, dim3((n + 63) / 64), dim3(64), 0, s, m.p, c.p, m4.p, c16.p, n);
+    YDS_HIP(hipMemcpyAsync(mean4_host, m4.p, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    YDS_HIP(hipMemcpyAsync(cov16_host, c16.p, (size_t)n * 64, hipMemcpyDeviceToHost, s));
     YDS_HIP(hipStreamSynchronize(s));
     YDS_API_END
 }

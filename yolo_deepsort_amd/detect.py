@@ -111,26 +111,84 @@ class FileVideoStream:
         return f if ok else None
 
     def _update(self):
-        while not self.stopped:
-            frame = self._next()
-            if frame is None:
-                break
-            if self.transform is not None:
-                frame = self.transform(frame)
-            self.Q.put(frame)
-        self.stopped = True
-        self.Q.put(None)                      # end marker wakes a blocked reader
+        import queue
+        try:
+            while not self.stopped:
+                frame = self._next()
+                if frame is None:
+                    break
+                if self.transform is not None:
+                    frame = self.transform(frame)
+                while not self.stopped:            # a full queue must not pin the thread once the consumer has gone
+                    try:
+                        self.Q.put(frame, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+        finally:
+            self.stopped = True
+            if self._cap is not None:              # released on the thread that reads it (never concurrently with read())
+                self._cap.release()
+            try:
+                self.Q.put_nowait(None)            # end marker wakes a blocked reader
+            except queue.Full:
+                pass
 
     def more(self):
         return not (self.stopped and self.Q.empty())
 
     def read(self):
-        return self.Q.get()
+        import queue
+        while True:
+            try:
+                return self.Q.get(timeout=0.05)
+            except queue.Empty:
+                if self.stopped and self.Q.empty():
+                    return None
+
+    def fps(self):
+        """CAP_PROP_FPS of a cv2 source (None for .npy / iterable sources)."""
+        if self._cap is None:
+            return None
+        import cv2
+        v = self._cap.get(cv2.CAP_PROP_FPS)
+        return float(v) if v and v > 0 else None
+
+    def seek_secs(self, skip_secs):
+        """video_detect.py:99-101: vid.set(CAP_PROP_POS_FRAMES, skip_secs * fps); before start().  .npy sources skip
+        skip_secs * 25 frames (no frame rate is stored with them)."""
+        if not skip_secs:
+            return
+        if self._thread is not None:
+            raise RuntimeError("seek_secs must be called before start()")
+        if self._cap is not None:
+            import cv2
+            self._cap.set(cv2.CAP_PROP_POS_FRAMES, int(skip_secs * (self.fps() or 25.0)))
+        else:
+            for _ in range(int(skip_secs * 25)):
+                if next(self._frames, None) is None:
+                    break
 
     def stop(self):
+        """Ends the reader thread (drains the queue so a blocked put() returns, joins) - safe when the consumer stops early."""
+        import queue
         self.stopped = True
-        if self._cap is not None:
+        t = self._thread
+        if t is not None and t.is_alive():
+            while t.is_alive():
+                try:
+                    while True:
+                        self.Q.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
+        elif t is None and self._cap is not None:
             self._cap.release()
+        try:
+            while True:
+                self.Q.get_nowait()
+        except queue.Empty:
+            pass
 
 
 def _transform(frame):
@@ -140,7 +198,7 @@ def _transform(frame):
 
 class VideoDetector:
     def __init__(self, model, class_path, thickness=2, font_path=None, font_size=10, thres=0.7, nms_thres=0.4,
-                 skip_frames=-1, fourcc="XVID", class_mask=None, win_size=None, overlap=0.15, tracker=None,
+                 skip_frames=-1, fourcc="mp4v", class_mask=None, win_size=None, overlap=0.15, tracker=None,
                  action_id=None, half=False, batch_frames=1):
         # batch_frames (not in the reference): with a tracker, read that many frames ahead and run them through the
         # batched device pipeline (csrc/pipeline.cpp) - same results per frame, yielded in order, ~10x the frame rate of
@@ -160,12 +218,18 @@ class VideoDetector:
         self.image_detector = ImageDetector(model, class_path, thickness=thickness, thres=thres, nms_thres=nms_thres,
                                             win_size=win_size, overlap=overlap, half=half)
 
-    def _frames(self, video_path):
+    def _frames(self, video_path, skip_secs=0):
+        self._source_fps = None
         if hasattr(video_path, "__iter__") and not isinstance(video_path, (str, bytes)):
+            if skip_secs:
+                raise ValueError("skip_secs needs a seekable source (a video file or an .npy path), not an iterable of frames")
             for f in video_path:           # already-decoded RGB frames
                 yield f
             return
-        fvs = FileVideoStream(video_path, _transform).start()       # video_detect.py:86: decode thread + BGR -> RGB
+        fvs = FileVideoStream(video_path, _transform)                # video_detect.py:86: decode thread + BGR -> RGB
+        self._source_fps = fvs.fps()
+        fvs.seek_secs(skip_secs)                                     # video_detect.py:99-101
+        fvs.start()
         try:
             while fvs.more():
                 frame = fvs.read()
@@ -191,10 +255,10 @@ class VideoDetector:
             detections = self.tracker.update(boxs.astype(np.float32), confidences, frame, class_ids)
         return detections
 
-    def _processed_batches(self, video_path):
+    def _processed_batches(self, video_path, skip_secs=0):
         """Groups of consecutive frames holding up to batch_frames frames that pass the skip_frames gate."""
         group, n_proc, frames = [], 0, 0
-        for frame in self._frames(video_path):
+        for frame in self._frames(video_path, skip_secs):
             if frame is None:
                 break
             proc = frames % self.skip_frames == 0
@@ -231,7 +295,7 @@ class VideoDetector:
             put_text(result, self._fps_text, (3, 15), 2, (255, 0, 0))
         return result
 
-    def _detect_batched(self, video_path, show_fps=True):
+    def _detect_batched(self, video_path, show_fps=True, skip_secs=0):
         """detect() through the batched pipeline: identical per-frame results, frames are read batch_frames ahead."""
         from . import _lib, pipeline as pl
         det = self.image_detector
@@ -245,7 +309,7 @@ class VideoDetector:
             fr = [f for f, proc in group if proc]
             return (_lib.DeviceBuffer.from_array(np.stack(fr, 0)), fr[0].shape[0], fr[0].shape[1], len(fr)) if fr else None
 
-        groups = self._processed_batches(video_path)
+        groups = self._processed_batches(video_path, skip_secs)
         cur = next(groups, None)
         cur_dev = upload(cur) if cur is not None else None
         while cur is not None:
@@ -273,7 +337,8 @@ class VideoDetector:
     def detect(self, video_path, output_path=None, skip_secs=0, real_show=False, show_fps=True):
         """Generator of (bgr_image, hold_detections, actions) like video_detect.py:78-199.  output_path: every result is
         also written - through cv2.VideoWriter when cv2 is installed, as one uint8 [N,H,W,3] array for a path ending in
-        ``.npy``; real_show needs cv2 (ignored without it); skip_secs needs a seekable cv2 capture (ignored otherwise)."""
+        ``.npy``; real_show needs cv2 (ignored without it); skip_secs seeks a cv2 capture to skip_secs * fps frames (an .npy
+        source skips skip_secs * 25 frames; an iterable of frames cannot seek and raises)."""
         writer, frames_out, cv2 = None, None, None
         try:
             import cv2 as _cv2
@@ -286,13 +351,14 @@ class VideoDetector:
             elif cv2 is None:
                 raise IOError("writing %s needs cv2 (or use an .npy path)" % output_path)
         try:
-            for result, det, actions in self._detect_impl(video_path, show_fps):
+            for result, det, actions in self._detect_impl(video_path, show_fps, skip_secs):
                 if frames_out is not None:
                     frames_out.append(result.copy())
                 elif output_path is not None:
                     if writer is None:
                         fourcc = cv2.VideoWriter_fourcc(*self.fourcc) if isinstance(self.fourcc, str) else self.fourcc
-                        writer = cv2.VideoWriter(output_path, fourcc, 25, (result.shape[1], result.shape[0]))
+                        # video_detect.py:91-96: the writer takes the SOURCE frame rate; 25 only where the source has none (.npy, iterables)
+                        writer = cv2.VideoWriter(output_path, fourcc, self._source_fps or 25, (result.shape[1], result.shape[0]))
                     writer.write(result)
                 if real_show and cv2 is not None:
                     cv2.imshow("result", result)
@@ -307,14 +373,14 @@ class VideoDetector:
             if real_show and cv2 is not None:
                 cv2.destroyAllWindows()
 
-    def _detect_impl(self, video_path, show_fps=True):
+    def _detect_impl(self, video_path, show_fps=True, skip_secs=0):
         # (the tracker-side NMS option reorders detections on the host, so it keeps the frame-by-frame path)
         if (self.batch_frames > 1 and self.tracker is not None and self.image_detector.win_size is None
                 and getattr(self.tracker, "nms_max_overlap", 1) == 1):
-            yield from self._detect_batched(video_path, show_fps)
+            yield from self._detect_batched(video_path, show_fps, skip_secs)
             return
         hold_detections, actions, frames = None, [], 0
-        for frame in self._frames(video_path):
+        for frame in self._frames(video_path, skip_secs):
             if frame is None:
                 break
             if frames % self.skip_frames == 0:

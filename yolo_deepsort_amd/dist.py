@@ -1,11 +1,46 @@
-"""Multi-GPU plumbing for the throughput run: one process per GPU, one independent video stream per
-rank (tracker state is per stream, reference deep_sort/deep_sort.py:41-44 ``clone()``), so the data path
-has NO collective.  torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU
-tests) is used only for the rendezvous, the timing barriers and the max-over-ranks reduction."""
+"""Multi-GPU plumbing of the stream-sharded run: one process per GPU, one independent video stream per rank
+(tracker state is per stream, reference deep_sort/deep_sort.py:41-44 ``clone()``), weights replicated.
+
+The exchange step - rank 0 collects every stream's int32 tracker rows once per frame batch - the timing barriers and the
+max / sum reductions run on RCCL DIRECTLY through libydsort's ``yds_comm_*`` group (csrc/comm.cpp: ncclCommInitRank from
+an id created by rank 0, ncclAllGather of the fixed block {count, rows[256][6]} per frame, ncclAllReduce) - backend "nccl".
+torch.distributed is only the host-side rendezvous that hands the 128-byte RCCL id to the other ranks (a gloo group over
+127.0.0.1: the launcher's MASTER_ADDR / MASTER_PORT contract); no torch CUDA call is made.  Backend "gloo" keeps
+everything on that host group: CPU tests, and the 2-ranks-on-one-GPU test (RCCL refuses two ranks on one device)."""
 
 from __future__ import annotations
 
+import ctypes as C
 import os
+
+import numpy as np
+
+MAX_ROWS = 256                       # YDS_COMM_MAX_ROWS
+BLOCK = 1 + MAX_ROWS * 6             # int32 per frame: count, rows[256][6]
+
+
+def pack_rows(outs):
+    """[rows or None per frame] -> int32 [batch, BLOCK] (count -1 = the detector returned None)."""
+    blk = np.zeros((len(outs), BLOCK), np.int32)
+    for b, o in enumerate(outs):
+        if o is None:
+            blk[b, 0] = -1
+            continue
+        o = np.asarray(o, np.int32).reshape(-1, 6)
+        if o.shape[0] > MAX_ROWS:
+            raise ValueError(f"{o.shape[0]} tracker rows in one frame exceed the exchange block ({MAX_ROWS})")
+        blk[b, 0] = o.shape[0]
+        blk[b, 1:1 + o.size] = o.reshape(-1)
+    return blk
+
+
+def unpack_rows(blk):
+    """int32 [batch, BLOCK] -> [rows or None per frame]"""
+    out = []
+    for row in np.asarray(blk, np.int32).reshape(-1, BLOCK):
+        n = int(row[0])
+        out.append(None if n < 0 else row[1:1 + n * 6].reshape(n, 6).copy())
+    return out
 
 
 class Ranks:
@@ -13,45 +48,76 @@ class Ranks:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.dist = None
-        self.backend = backend
+        self.backend = backend or "nccl"
+        self.dist = None                 # host-side group (gloo)
+        self.comm = None                 # yds_comm handle (RCCL) once connect() ran
         if self.world > 1:
-            import torch
             import torch.distributed as dist
-            backend = backend or "nccl"
-            if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
-            else:
-                dist.init_process_group(backend)
+            dist.init_process_group("gloo")
             self.dist = dist
-            self.backend = backend
+
+    def connect(self):
+        """Create the RCCL communicator on the device this process is bound to (after _lib.init()).  No-op for one rank or
+        the gloo backend."""
+        if self.world == 1 or self.backend != "nccl" or self.comm is not None:
+            return self
+        from . import _lib
+        lib = _lib.load()
+        _lib.init()
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(lib.yds_comm_unique_id(ident))
+        box = [bytes(ident.raw)]
+        self.dist.broadcast_object_list(box, src=0)
+        self.comm = _lib.check_ptr(lib.yds_comm_create(C.create_string_buffer(box[0], 128), self.world, self.rank))
+        return self
 
     def stream_seed(self, base=0):
         """Each rank synthesises its own stream: seed = base + rank (seeds 0-7)."""
         return base + self.rank
 
     def barrier(self):
-        if self.dist is not None:
+        if self.comm is not None:
+            from . import _lib
+            _lib.check(_lib.load().yds_comm_barrier(self.comm))
+        elif self.dist is not None:
             self.dist.barrier()
 
-    def max_over_ranks(self, value):
+    def _reduce(self, value, op):
+        if self.comm is not None:
+            from . import _lib
+            v = (C.c_double * 1)(float(value))
+            _lib.check(_lib.load().yds_comm_allreduce_f64(self.comm, v, 1, op))
+            return float(v[0])
         if self.dist is None:
             return float(value)
         import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == 1 else self.dist.ReduceOp.SUM)
         return float(t.item())
 
+    def max_over_ranks(self, value):
+        return self._reduce(value, 1)
+
     def sum_over_ranks(self, value):
-        if self.dist is None:
-            return float(value)
-        import torch
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        return float(t.item())
+        return self._reduce(value, 0)
+
+    def gather_rows(self, outs):
+        """The exchange step: every rank hands in the rows of its stream for one frame batch ([rows or None] per frame) and
+        receives [stream 0's list, stream 1's list, ...] - what rank 0 emits for the whole job."""
+        if self.world == 1:
+            return [outs]
+        blk = pack_rows(outs)
+        allb = np.zeros((self.world,) + blk.shape, np.int32)
+        if self.comm is not None:
+            from . import _lib
+            _lib.check(_lib.load().yds_comm_allgather(self.comm, _lib.ptr(blk), blk.nbytes, _lib.ptr(allb)))
+        else:
+            import torch
+            parts = [torch.zeros(blk.shape, dtype=torch.int32) for _ in range(self.world)]
+            self.dist.all_gather(parts, torch.from_numpy(blk))
+            allb = np.stack([p.numpy() for p in parts], 0)
+        return [unpack_rows(allb[r]) for r in range(self.world)]
 
     def gather_objects(self, obj):
         """[obj of rank 0, obj of rank 1, ...] on every rank (small host objects: device ids, per-rank rates)."""
@@ -66,6 +132,10 @@ class Ranks:
         return steps * frames_per_step * self.world
 
     def shutdown(self):
+        if self.comm is not None:
+            from . import _lib
+            _lib.load().yds_comm_destroy(self.comm)
+            self.comm = None
         if self.dist is not None:
             self.dist.destroy_process_group()
             self.dist = None

@@ -75,7 +75,17 @@ class _LazyTensor:
         if flat is None:
             raise ValueError(f"storage {self.storage.key} was never read")
         item = flat.dtype.itemsize
-        v = np.lib.stride_tricks.as_strided(flat[self.offset:], shape=self.size, strides=tuple(st * item for st in self.stride))
+        # the geometry comes straight from the (untrusted) pickle: every element it addresses must lie inside the storage
+        size, stride = tuple(int(n) for n in self.size), tuple(int(st) for st in self.stride)
+        if len(size) != len(stride) or self.offset < 0 or any(n < 0 for n in size) or any(st < 0 for st in stride):
+            raise ValueError(f"tensor geometry of storage {self.storage.key} is malformed (offset {self.offset}, size {size}, stride {stride})")
+        if all(n > 0 for n in size):        # (an empty tensor addresses nothing)
+            last = self.offset + sum((n - 1) * st for n, st in zip(size, stride))
+            if last >= flat.size:
+                raise ValueError(f"tensor of storage {self.storage.key} reaches element {last} of {flat.size}: refused")
+        else:
+            return np.zeros(size, dtype=flat.dtype)
+        v = np.lib.stride_tricks.as_strided(flat[self.offset:], shape=size, strides=tuple(st * item for st in stride))
         return np.array(v)            # contiguous copy (0-dim tensors included)
 
 
@@ -157,6 +167,8 @@ def read_torch_checkpoint(path):
             numel = int(np.frombuffer(f.read(8), dtype="<i8")[0])
             if st is None:
                 raise ValueError(f"{path}: storage {key} is not referenced by the object")
+            if numel != st.numel or numel < 0:
+                raise ValueError(f"{path}: storage {key} holds {numel} elements, the object expects {st.numel}")
             st.data = np.frombuffer(f.read(numel * st.dtype.itemsize), dtype=st.dtype, count=numel)
     return _materialise(obj)
 

@@ -13,6 +13,11 @@ from . import _lib
 class Pipeline:
     def __init__(self, net, deepsort, conf_thres=0.5, nms_thres=0.4, class_mask=None, cap=512):
         self.net, self.ds, self.cap = net, deepsort, int(cap)
+        # the batched path hands the tracker handle to the C pipeline and never passes through DeepSort.update: the
+        # tracker-side NMS (deep_sort.py:52-57, a host-ordered reordering of the detections) is not part of it
+        if getattr(deepsort, "nms_max_overlap", 1) != 1:
+            raise ValueError("Pipeline: DeepSort(nms_max_overlap=%r) needs the frame-by-frame path (DeepSort.update / "
+                             "VideoDetector(batch_frames=1)); the batched pipeline has no tracker-side NMS" % (deepsort.nms_max_overlap,))
         mask = np.ascontiguousarray(class_mask if class_mask is not None else [], dtype=np.int32)
         self._h = _lib.check_ptr(_lib.load().yds_pipeline_create(net._h, deepsort.extractor._h, deepsort.tracker._h,
                                                                  conf_thres, nms_thres,
@@ -64,11 +69,11 @@ def conv_timing(net, mode=0):
     """Per tile-variant (total_us, launches, flops, name) of the conv kernel; mode 1 resets+starts, 2 stops."""
     lib = _lib.load()
     nv = lib.yds_conv_num_variants()
-    us = (C.c_double * nv)()
+    us, fl, by, at = ((C.c_double * nv)() for _ in range(4))
     n = (C.c_int64 * nv)()
-    fl = (C.c_double * nv)()
-    _lib.check(lib.yds_conv_timing(net._h, mode, us, n, fl))
-    return [dict(name=lib.yds_conv_variant_name(v).decode(), us=us[v], launches=n[v], flops=fl[v]) for v in range(nv)]
+    _lib.check(lib.yds_conv_timing_ex(net._h, mode, us, n, fl, by, at))
+    return [dict(name=lib.yds_conv_variant_name(v).decode(), us=us[v], launches=n[v], flops=fl[v], bytes=by[v], attainable_us=at[v])
+            for v in range(nv)]
 
 
 def load_injection_sets(net, sets, logit=6.0):
