@@ -53,6 +53,50 @@ def test_pipeline_at_bench_shape_vs_reference(config):
         np.testing.assert_allclose(det, ref, rtol=1e-3, atol=1e-3)
 
 
+def test_cfg4_second_stream_vs_reference():
+    """BASELINE configs[3] (cfg4 = yolov4 + DeepSORT, one stream per GPU, stream seed = rank): rank 1's stream (seed 1) for one
+    step of 16 frames against the reference's run on the same frames (rank 0's stream is bench_shape_cfg3)."""
+    from yolo_deepsort_amd.workload import Workload
+    g = golden("bench_shape_cfg4_seed1")
+    wl = Workload("cfg4", batch=16, seed=1)
+    assert int(g["n_frames"]) == 16
+    outs = wl.step(0, prefetch=False)
+    stats = [0, 0]
+    for t, o in enumerate(outs):
+        if bool(g[f"f{t}_none"]):
+            assert o is None, t
+            continue
+        _rows_equal(o, g[f"f{t}_out"], stats)
+    st = wl.ds.tracker.state()
+    assert np.array_equal(st["ids"], g["f15_ids"]) and np.array_equal(st["state"], g["f15_state"])
+    assert stats[1] > 1000 and stats[0] / stats[1] < 5e-3, stats
+
+
+@pytest.mark.parametrize("config", ["cfg2", "cfg3"])
+def test_frame_by_frame_at_bench_shape_vs_reference(config):
+    """The latency mode bench.py reports as value_frame_by_frame: batch_frames = 1, nothing enqueued ahead - the detector runs
+    on ONE 608x608 image (split-K kernels, other tile choices than at batch 16).  32 frames against the reference's rows."""
+    from yolo_deepsort_amd.workload import Workload, CONF_THRES, NMS_THRES
+    g = golden(f"bench_shape_{config}")
+    wl = Workload(config, batch=1, n_distinct=32)
+    stats = [0, 0]
+    for t in range(32):
+        o = wl.step(t, prefetch=(t % 2 == 1 and t + 1 < 32))[0]          # alternate the strict and the 1-frame look-ahead form
+        if bool(g[f"f{t}_none"]):
+            assert o is None, t
+            continue
+        _rows_equal(o, g[f"f{t}_out"], stats)
+    st = wl.ds.tracker.state()
+    assert np.array_equal(st["ids"], g["f31_ids"]) and np.array_equal(st["state"], g["f31_state"])
+    assert stats[1] > 2000 and stats[0] / stats[1] < 5e-3, stats
+    wl._pl.select_injection_set(wl.net, 16)
+    pred = wl.net.forward_u8(wl.ring[16:17])
+    np.testing.assert_allclose(pred[0].reshape(-1)[g["sample_idx"]], g["f16_pred"], rtol=1e-3, atol=1e-3)
+    det = wl.net.nms(0, CONF_THRES, NMS_THRES, frame_hw=(wl.H, wl.W))
+    assert det.shape == g["f16_det"].shape and np.array_equal(det[:, 5], g["f16_det"][:, 5])
+    np.testing.assert_allclose(det, g["f16_det"], rtol=1e-3, atol=1e-3)
+
+
 def test_forward_f32_batch16_608_vs_oracle():
     """Raw-tensor entry at batch 16, 608x608 (yolov3): two of the 16 images against the oracle's full tensors."""
     from oracle.darknet import DarknetOracle

@@ -100,7 +100,7 @@ int conv_default_variant(const ConvArgs &a);
 // 3x3 RGB stem + MaxPool2d(3, 2, 1) in one kernel (ReID); a.y is the pooled view.  Returns false when the layer does not qualify.
 bool launch_conv_maxpool3s2(const ConvArgs &a, hipStream_t s);
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us);   // measured fastest variant
-constexpr int kF32Variants = 7, kDirectVariant = 21, kConvVariants = 22;   // ids 0-6: fp32 MFMA tiles, 7-20: f16x3 tiles, 21: direct RGB 3x3
+constexpr int kF32Variants = 7, kDirectVariant = 23, kConvVariants = 24;   // ids 0-6: fp32 MFMA tiles, 7-22: f16x3 tiles, 23: direct RGB 3x3
 enum ConvMath { MATH_F32 = 0, MATH_F16X3 = 1 };
 int conv_math();                 // process-wide arithmetic mode (env YDS_CONV_MATH=f32|f16x3, default f16x3)
 void set_conv_math(int m);

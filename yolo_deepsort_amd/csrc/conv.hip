@@ -358,7 +358,9 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
     if (const char *f = getenv("YDS_CONV_FORCE")) {      // tuning aid: pin a variant id where it is applicable
         int v = atoi(f);
         const bool f16v = v >= kF32Variants && v != kDirectVariant;
-        const bool presplit = f16v && (f16_variant_is_dma(v - kF32Variants) || f16_variant_is_win(v - kF32Variants) || f16_variant_is_win2(v - kF32Variants));
+        const bool presplit = f16v && (f16_variant_is_dma(v - kF32Variants) || f16_variant_is_win(v - kF32Variants) || f16_variant_is_win2(v - kF32Variants) ||
+                                       f16_variant_is_splitk(v - kF32Variants));
+        if (f16v && f16_variant_is_splitk(v - kF32Variants) && !conv_splitk_applicable(make_conv_args(a), v - kF32Variants)) return conv_autotune_measured(a, s, best_us);
         if (v == kDirectVariant && !conv_direct_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (f16v && f16_variant_is_win(v - kF32Variants) && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (f16v && f16_variant_is_win2(v - kF32Variants) && !conv_win2_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
@@ -391,7 +393,8 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
         const int fv = v - kF32Variants;                // f16x3 variant index (meaningful for kF32Variants <= v < kDirectVariant)
         const bool f16v = v >= kF32Variants && v != kDirectVariant;
-        if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv) || f16_variant_is_win2(fv)) && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // need a pre-split input
+        if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv) || f16_variant_is_win2(fv) || f16_variant_is_splitk(fv)) && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // need a pre-split input
+        if (f16v && f16_variant_is_splitk(fv) && !conv_splitk_applicable(make_conv_args(a), fv)) continue;
         if (f16v && f16_variant_is_win2(fv) && (!conv_win2_applicable(make_conv_args(a)) || a.y.c < 128)) continue;
         if (f16v && f16_variant_is_win(fv) && !conv_win_applicable(make_conv_args(a))) continue;
         if (f16v && f16_variant_is_win(fv) && fv > 8 && a.y.c > 64) continue;          // 64-wide window tiles are for 64-filter layers

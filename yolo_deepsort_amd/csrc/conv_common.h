@@ -30,6 +30,7 @@ struct ConvKernelArgs {
     int act, res_mode;
     int fmt_x, fmt_y, fmt_r;              // TensorFmt of input, output and residual views
     int terms;                            // 3: f16x3, 1: hi halves only (half mode; LDS-DMA and window kernels)
+    int ksplit = 1;                       // LDS-DMA kernel: K ranges (grid.y); > 1 writes raw partial sums into slab blockIdx.y of y
     // XCD-aware tile map: the 8 XCDs own an xm x xn grid of rectangles of rm x rn tiles (workgroup id % 8 = XCD)
     int tiles_m, tiles_n, xm, rm, rn;
 };
@@ -249,10 +250,12 @@ bool conv_pool_applicable(const ConvKernelArgs &k);
 void launch_conv_pool(const ConvKernelArgs &k, hipStream_t s);
 
 // split-fp16 path (conv_f16x3.hip)
-constexpr int kF16Variants = 14;           // 0-3 register-staged tiles, 4-7 and 11-12 LDS-DMA ring, 8-10 window-resident 3x3, 13 window-resident with two workgroups per CU (pre-split inputs only)
+constexpr int kF16Variants = 16;           // 0-3 register-staged tiles, 4-7 and 11-12 LDS-DMA ring, 8-10 window-resident 3x3, 13 window-resident with two workgroups per CU, 14-15 LDS-DMA ring with split-K + reduce pass (pre-split inputs only)
 inline bool f16_variant_is_dma(int v) { return (v >= 4 && v <= 7) || v == 11 || v == 12; }
 inline bool f16_variant_is_win(int v) { return v >= 8 && v <= 10; }
 inline bool f16_variant_is_win2(int v) { return v == 13; }
+inline bool f16_variant_is_splitk(int v) { return v == 14 || v == 15; }
+bool conv_splitk_applicable(const ConvKernelArgs &k, int fv);     // a split of >= 2 K ranges exists and pays (few tiles, long K)
 // two-workgroup window kernel (conv_win2.hip): 128x128 tiles, 4 waves, 16-channel K steps
 bool conv_win2_applicable(const ConvKernelArgs &k);
 void launch_conv_win2(ConvKernelArgs k, hipStream_t s);

@@ -17,6 +17,8 @@
 // free, XCD-aware tile map, compile-time epilogue.
 #include "conv_common.h"
 
+#include <map>
+
 #include <math.h>
 #include <string.h>
 
@@ -310,7 +312,21 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         const int row = (q * NW + wave) * 8 + drow;
         w_src[q] = reinterpret_cast<const char *>(p.w) + (size_t)min(n0 + row, p.Cout - 1) * p.Kpad * 4 + src_chunk(q);
     }
-    int kh = 0, kw = 0, kc = 0;                                 // (tap, channel group) of the next tile to issue
+    // split-K (gridDim.y > 1): this workgroup accumulates K tiles [t_begin, t_begin + nk) only and writes raw fp32 partial
+    // sums into slab blockIdx.y of the workspace p.y (the launcher passes zero bias / linear / no residual / fp32 output);
+    // splitk_reduce_kernel adds the slabs in a fixed order and applies the real epilogue.
+    const int nk_all = p.K / 32;                                // Cin % 32 == 0 on this path
+    int t_begin = 0, nk = nk_all;
+    if (gridDim.y > 1) {
+        const int per = (nk_all + gridDim.y - 1) / gridDim.y;
+        t_begin = blockIdx.y * per;
+        nk = max(0, min(nk_all, t_begin + per) - t_begin);
+        p.y += (size_t)blockIdx.y * (size_t)p.M * p.ldy;
+    }
+    const int kcs = p.Cin / 32;
+    int kh = (t_begin / kcs) / p.ksize, kw = (t_begin / kcs) % p.ksize, kc = (t_begin % kcs) * 32;   // (tap, channel group) of the next tile to issue
+#pragma unroll
+    for (int q = 0; q < B_INST; ++q) w_src[q] += (size_t)t_begin * 128;
     auto set_tap = [&]() {
 #pragma unroll
         for (int q = 0; q < A_INST; ++q) {
@@ -344,7 +360,6 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
-    const int nk = p.K / 32;                                    // Cin % 32 == 0 on this path
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) {
@@ -473,7 +488,7 @@ template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS> s
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    dim3 grid(plan_tile_map(k, BM, BN));
+    dim3 grid(plan_tile_map(k, BM, BN), k.ksplit > 1 ? k.ksplit : 1);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, s, k, zero_page_dev());
     YDS_HIP(hipGetLastError());
 }
@@ -490,6 +505,86 @@ template <int BM, int BN, int WM, int WN, int NS> static void launch_cfg_dma(con
 #define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R, 3>(k, s)
     YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-K (small batches: the frame-by-frame API runs the detector on ONE image, where a 19x19 layer has 24-48 tiles for
+// 256 CUs and every workgroup streams its whole filter slice - megabytes - through a ring that holds two K steps; the
+// launch is bound by the latency of that stream, not by the matrix cores).  The K tiles are cut into `ksplit` ranges,
+// grid.y = ksplit workgroups per output tile accumulate one range each (more independent filter streams in flight) and
+// write raw fp32 partial sums into a workspace slab; splitk_reduce_kernel adds the slabs in slab order (deterministic:
+// the same bits on every run) and applies bias, activation, residual and the output format.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, int ksplit, int M, int ldw, ConvKernelArgs p) {
+    const int c4 = (p.Cout + 3) / 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * c4) return;
+    const int m = idx / c4, n = (idx - m * c4) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ksplit; ++z) {
+        const float4 t = *reinterpret_cast<const float4 *>(ws + ((size_t)z * M + m) * ldw + n);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = n + 3 < p.Cout;
+    if (p.res_mode != RES_NONE) {
+        const float *rp = p.res + (size_t)m * p.ldr;
+        if (p.fmt_r == FMT_H16 || full) load4(rp, n, p.fmt_r, r);
+        else for (int k = 0; k < 4; ++k) if (n + k < p.Cout) r[k] = rp[n + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o = v[k] + (n + k < p.Cout ? p.bias[n + k] : 0.f);
+        if (p.res_mode == RES_BEFORE_ACT) o += r[k];
+        o = p.act == ACT_LEAKY ? apply_act<ACT_LEAKY>(o) : p.act == ACT_MISH ? apply_act<ACT_MISH>(o) : p.act == ACT_RELU ? apply_act<ACT_RELU>(o) : o;
+        if (p.res_mode == RES_AFTER_ACT) o += r[k];
+        v[k] = o;
+    }
+    float *yp = p.y + (size_t)m * p.ldy;
+    if (p.fmt_y == FMT_H16 || full) store4(yp, n, p.fmt_y, v);
+    else for (int k = 0; k < 4; ++k) if (n + k < p.Cout) yp[n + k] = v[k];
+}
+
+// number of K ranges for a BM x BN tiling: enough workgroups for two per CU, at least four K tiles per range
+int conv_splitk_factor(const ConvKernelArgs &k, int BM, int BN) {
+    const long tiles = (long)((k.M + BM - 1) / BM) * ((k.Cout + BN - 1) / BN);
+    const int nk = k.K / 32;
+    int s = (int)((512 + tiles - 1) / tiles);
+    s = std::min(s, std::min(16, nk / 4));
+    return s >= 2 ? s : 1;
+}
+
+static float *splitk_workspace(size_t floats, hipStream_t s) {
+    // one grow-only slab set per stream (the detector and the ReID network run concurrently on their own streams)
+    static std::map<hipStream_t, DevBuf<float>> bufs;
+    DevBuf<float> &b = bufs[s];
+    if (b.n < floats) {
+        YDS_HIP(hipStreamSynchronize(s));
+        b.alloc(floats + floats / 2);
+    }
+    return b.p;
+}
+
+template <int BM, int BN> static void launch_splitk(const ConvKernelArgs &k, hipStream_t s) {
+    if (k.fmt_x != FMT_H16 || k.Cin % 32) fail("conv: the split-K LDS-DMA kernel needs a pre-split (H16) input");
+    if ((size_t)k.Cout * 4 > (size_t)ZERO_PAGE_BYTES) fail("conv: %d filters exceed the zero page used as the split-K bias", k.Cout);
+    const int ksplit = conv_splitk_factor(k, BM, BN);
+    if (ksplit < 2) fail("conv: split-K does not apply (the layer already has enough tiles or too few K steps)");
+    const int ldw = (k.Cout + 3) / 4 * 4;
+    float *ws = splitk_workspace((size_t)ksplit * k.M * ldw, s);
+    ConvKernelArgs part = k;
+    part.y = ws; part.ldy = ldw; part.fmt_y = FMT_F32;
+    part.bias = reinterpret_cast<const float *>(zero_page_dev());
+    part.res = nullptr; part.res_mode = RES_NONE; part.fmt_r = FMT_F32; part.act = ACT_LINEAR;
+    part.ksplit = ksplit;
+    launch_cfg_dma<BM, BN, 2, 2, 2>(part, s);
+    const int c4 = (k.Cout + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(((size_t)k.M * c4 + 255) / 256), dim3(256), 0, s, ws, ksplit, k.M, ldw, k);
+    YDS_HIP(hipGetLastError());
+}
+
+bool conv_splitk_applicable(const ConvKernelArgs &k, int fv) {
+    if (k.fmt_x != FMT_H16 || k.Cin % 32) return false;
+    return fv == 14 ? conv_splitk_factor(k, 64, 128) >= 2 : conv_splitk_factor(k, 128, 128) >= 2;
 }
 
 template <int BM, int BN, int ACT, int RES, int AIN> static void launch_inst16(ConvKernelArgs k, hipStream_t s) {
@@ -530,7 +625,8 @@ const char *conv_f16x3_variant_name(int v) {
                                               "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,2x2,2>", "conv_igemm_f16x3_dma<256,128,4x2,3>",
                                               "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>", "conv3x3_f16x3_win<256,128,4x2>",
                                               "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>",
-                                              "conv_igemm_f16x3_dma<128,64,2x2,2>", "conv_igemm_f16x3_dma<64,128,2x2,2>", "conv3x3_f16x3_win2<128,128,2x2>"};
+                                              "conv_igemm_f16x3_dma<128,64,2x2,2>", "conv_igemm_f16x3_dma<64,128,2x2,2>", "conv3x3_f16x3_win2<128,128,2x2>",
+                                              "conv_igemm_f16x3_dma<64,128,2x2,2>+splitK", "conv_igemm_f16x3_dma<128,128,2x2,2>+splitK"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
 }
 
@@ -551,6 +647,8 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s) {
         // the 1x1 layers at 76^2 / 38^2 / 19^2 run 1.4 rounds of 128x128 tiles on 512 slots, i.e. pay for 2
         case 11: launch_cfg_dma<128, 64, 2, 2, 2>(k, s); break;
         case 13: launch_conv_win2(k, s); break;
+        case 14: launch_splitk<64, 128>(k, s); break;
+        case 15: launch_splitk<128, 128>(k, s); break;
         default: launch_cfg_dma<64, 128, 2, 2, 2>(k, s); break;
     }
 }
