@@ -386,6 +386,31 @@ def test_lsap_bit_exact_vs_scipy_and_oracle():
         r1, c1 = _lsap(c)
         assert np.array_equal(r0, r1) and np.array_equal(c0, c1), shape
     assert _lsap(np.ones((4, 4)))[1].tolist() == [0, 1, 2, 3]
+    # the register-resident workgroup form (64 < columns <= 256): every tie structure again at those sizes, tall and wide
+    for trial in range(60):
+        nr, nc = (int(v) for v in rng.randint(1, 257, 2))
+        if max(nr, nc) <= 64:
+            nc = 65 + trial
+        kind = trial % 4
+        if kind == 0:
+            c = rng.rand(nr, nc).astype(F32)
+        elif kind == 1:
+            c = rng.randint(0, 3, (nr, nc)).astype(F32)
+        elif kind == 2:
+            c = rng.rand(nr, nc).astype(F32)
+            c[c > 0.3] = F32(0.30001)
+        else:
+            c = np.full((nr, nc), 0.70001, F32)
+            m = rng.rand(nr, nc) < 0.05
+            c[m] = rng.rand(m.sum())
+        r0, c0 = linear_sum_assignment(c)
+        r1, c1 = _lsap(c)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), (trial, nr, nc, kind)
+    for shape in ((256, 256), (256, 1), (1, 256), (255, 256), (65, 65), (200, 150)):
+        c = np.full(shape, F32(0.5))
+        r0, c0 = linear_sum_assignment(c)                       # all ties: the order of scipy's scan decides everything
+        r1, c1 = _lsap(c)
+        assert np.array_equal(r0, r1) and np.array_equal(c0, c1), shape
 
 
 # ----------------------------------------------------------------------------------------- traces
