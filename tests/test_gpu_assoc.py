@@ -176,7 +176,10 @@ def test_tiled_detection_golden():
             assert np.array_equal(out[:, 5], ref[:, 5])
             np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL, equal_nan=True)
             outs.append(out)
-        assert np.array_equal(outs[0], outs[1], equal_nan=True) and np.array_equal(outs[0], outs[2], equal_nan=True)
+        # (the windows of one frame in one batch or in chunks: the same boxes; low bits may differ - a batch of one window
+        #  takes the split-K kernels on its deep layers, which add the K ranges in another order)
+        for o in outs[1:]:
+            np.testing.assert_allclose(o, outs[0], rtol=1e-5, atol=1e-4, equal_nan=True)
     # a frame smaller than the window takes the plain path (img_detect.py:67)
     small = np.random.RandomState(1).randint(0, 256, (300, 400, 3)).astype(np.uint8)
     det = _tiled_detector(-1.3, 1)

@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <string>
 #include <vector>
 
 #include "ydsort.h"
@@ -23,6 +24,7 @@ namespace {
 
 struct Rccl {
     void *h = nullptr;
+    std::string path;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -35,10 +37,28 @@ struct Rccl {
 Rccl &rccl() {
     static Rccl r;
     if (r.h) return r;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.h) break;
+    // The RCCL that belongs to the HIP runtime THIS library runs on: a Python process may hold two ROCm stacks (torch
+    // ships its own libamdhip64 / librccl next to /opt/rocm's), and an RCCL resolved by bare name can be the other stack's -
+    // its HIP calls then fail on this runtime's streams ("unhandled cuda error" in ncclCommInitRank).  So: the directory
+    // of the libamdhip64 that hipGetDeviceCount resolves to, by absolute path (a path with a slash is never matched
+    // against an already-loaded library of the same SONAME); bare names only as a fallback.
+    std::vector<std::string> names;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash);
+            names.push_back(dir + "/librccl.so.1");
+            names.push_back(dir + "/librccl.so");
+        }
+    }
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const std::string &n : names) {
+        r.h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (r.h) { r.path = n; break; }
     }
     if (!r.h) fail("comm: librccl not found (%s); multi-GPU runs need RCCL", dlerror());
     auto sym = [&](const char *n) {

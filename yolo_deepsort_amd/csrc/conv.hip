@@ -366,6 +366,7 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
         if (f16v && f16_variant_is_win2(v - kF32Variants) && !conv_win2_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (!(presplit && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
+    if (conv_math() == MATH_F16X3 && a.w16 && a.terms != 1 && conv_splitk_preferred(make_conv_args(a))) return kF32Variants + 14;   // by rule (see there)
     const std::string key = tune_key(a);
     auto &cache = tune_cache();
     auto it = cache.find(key);
@@ -394,7 +395,7 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
         const int fv = v - kF32Variants;                // f16x3 variant index (meaningful for kF32Variants <= v < kDirectVariant)
         const bool f16v = v >= kF32Variants && v != kDirectVariant;
         if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv) || f16_variant_is_win2(fv) || f16_variant_is_splitk(fv)) && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // need a pre-split input
-        if (f16v && f16_variant_is_splitk(fv) && !conv_splitk_applicable(make_conv_args(a), fv)) continue;
+        if (f16v && f16_variant_is_splitk(fv)) continue;                                  // selected by rule in conv_autotune, never by timing
         if (f16v && f16_variant_is_win2(fv) && (!conv_win2_applicable(make_conv_args(a)) || a.y.c < 128)) continue;
         if (f16v && f16_variant_is_win(fv) && !conv_win_applicable(make_conv_args(a))) continue;
         if (f16v && f16_variant_is_win(fv) && fv > 8 && a.y.c > 64) continue;          // 64-wide window tiles are for 64-filter layers

@@ -255,7 +255,8 @@ inline bool f16_variant_is_dma(int v) { return (v >= 4 && v <= 7) || v == 11 || 
 inline bool f16_variant_is_win(int v) { return v >= 8 && v <= 10; }
 inline bool f16_variant_is_win2(int v) { return v == 13; }
 inline bool f16_variant_is_splitk(int v) { return v == 14 || v == 15; }
-bool conv_splitk_applicable(const ConvKernelArgs &k, int fv);     // a split of >= 2 K ranges exists and pays (few tiles, long K)
+bool conv_splitk_applicable(const ConvKernelArgs &k, int fv);     // a split of >= 2 K ranges exists
+bool conv_splitk_preferred(const ConvKernelArgs &k);              // the deterministic rule that selects variant 14 (never timed against the others)
 // two-workgroup window kernel (conv_win2.hip): 128x128 tiles, 4 waves, 16-channel K steps
 bool conv_win2_applicable(const ConvKernelArgs &k);
 void launch_conv_win2(ConvKernelArgs k, hipStream_t s);

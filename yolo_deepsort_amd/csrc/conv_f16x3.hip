@@ -582,6 +582,15 @@ template <int BM, int BN> static void launch_splitk(const ConvKernelArgs &k, hip
     YDS_HIP(hipGetLastError());
 }
 
+// Split-K is chosen by RULE, not by the autotuner's stopwatch: it changes the fp32 summation order, so a timing-dependent
+// choice would let the low bits of a result vary from run to run.  Few tiles (less than half the chip at 64 x 128) and a
+// long K (>= 32 steps): the 19x19 / 38x38 layers of a one-image detector pass, the last ReID stages of a small crop batch.
+bool conv_splitk_preferred(const ConvKernelArgs &k) {
+    if (k.fmt_x != FMT_H16 || k.Cin % 32) return false;
+    const long tiles = (long)((k.M + 63) / 64) * ((k.Cout + 127) / 128);
+    return tiles <= 128 && k.K / 32 >= 32 && conv_splitk_factor(k, 64, 128) >= 2;
+}
+
 bool conv_splitk_applicable(const ConvKernelArgs &k, int fv) {
     if (k.fmt_x != FMT_H16 || k.Cin % 32) return false;
     return fv == 14 ? conv_splitk_factor(k, 64, 128) >= 2 : conv_splitk_factor(k, 128, 128) >= 2;

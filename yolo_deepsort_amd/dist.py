@@ -52,6 +52,9 @@ class Ranks:
         self.dist = None                 # host-side group (gloo)
         self.comm = None                 # yds_comm handle (RCCL) once connect() ran
         if self.world > 1:
+            # libydsort (and with it the HIP runtime it is linked against) is mapped BEFORE torch brings its own ROCm libraries
+            from . import _lib
+            _lib.load()
             import torch.distributed as dist
             dist.init_process_group("gloo")
             self.dist = dist
