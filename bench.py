@@ -145,8 +145,10 @@ def main():
         _lib.check(lib.yds_device_sync())
 
     # ---- the metric: frames resident in HBM
+    pl.conv_clock(reset=True)
     kept = [] if args.dump_rows else None
     dt, n_out = timed_steps(wl, ranks, sync, K, W, 0, host_frames=False, keep=kept)     # n_out: rows of ALL streams (gathered on every rank)
+    clock_ghz, clock_ms = pl.conv_clock(reset=True)              # shader clock inside the window kernels over the K timed steps (+ warm-up)
     if kept is not None and rank == 0:
         import numpy as np
         arrays = {}
@@ -216,7 +218,12 @@ def main():
                                                   us_per_frame_overlapped=round(allc["measured_us"] / ((K + W) * B), 1)),
                             # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
                             # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
-                            pipeline_conv_frac=round(flops_frame * frames_total_for_frac / dt / 1e12 / peak, 4))
+                            pipeline_conv_frac=round(flops_frame * frames_total_for_frac / dt / 1e12 / peak, 4),
+                            # the peak assumes 2.4 GHz; the chip is power limited under this load: clock sampled INSIDE the window
+                            # kernels (s_memtime / s_memrealtime, one workgroup in 32) over the timed region
+                            sustained_clock_ghz=round(clock_ghz, 3), nominal_clock_ghz=2.4,
+                            peak_at_sustained_clock=round(peak * clock_ghz / 2.4, 1) if clock_ghz else None,
+                            frac_at_sustained_clock=round(dom["achieved"] / (peak * clock_ghz / 2.4), 4) if clock_ghz else None)
             # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
             # the committed rocprofv3 --pmc passes over this same command (tools/profile_bench.sh, PMC=1)
             for rnd in ("r03", "r02", "r01"):

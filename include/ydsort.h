@@ -251,7 +251,13 @@ const char *yds_conv_variant_name(int variant);
  * average launch duration in us and the tile variant that was picked. */
 int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual,
                    int iters, double *avg_us, int *variant);
-/* tuning aid (YDS_TIMING experiment builds only): accumulated s_memtime phase counters of the LDS-DMA conv kernel */
+/* Shader clock the chip sustained INSIDE the window-resident conv kernels since the last reset: one workgroup in 32 samples
+ * s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end; *ghz = cycles / time over all samples,
+ * *sampled_ms = the workgroup time that was sampled.  The dense-MFMA peaks are quoted at 2.4 GHz; under this load the chip
+ * is power limited well below that, which bench.py reports next to the nominal roofline fraction. */
+int yds_conv_clock(double *ghz, double *sampled_ms, int reset);
+/* tuning aid (YDS_TIMING / YDS_TIMING2 experiment builds only): accumulated s_memtime phase counters of the LDS-DMA conv kernel
+ * (reset = 0 / 1) or of the two-workgroup window kernel (reset = 2 / 3: wait, barrier, body, prologue, epilogue, total, steps, waves) */
 int yds_debug_prof(uint64_t *out8, int reset);
 /* parity-test entry: one convolution through a chosen kernel variant (formats as the planner would pick them for the
  * current conv math).  x NHWC [n,h,w,cin], w [cout][kh][kw][cin] (BN already folded), res NHWC or NULL

@@ -64,6 +64,7 @@ SIGNATURES = {
     "yds_conv_variant_name": (C.c_char_p, [_I]),
     "yds_conv_timing_ex": (_I, [_P, _I, _P, _P, _P, _P, _P]),
     "yds_conv_num_variants": (_I, []),
+    "yds_conv_clock": (_I, [_P, _P, _I]),
     "yds_set_conv_math": (_I, [_I]),
     "yds_get_conv_math": (_I, []),
     "yds_conv_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),

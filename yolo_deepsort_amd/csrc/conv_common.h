@@ -265,6 +265,10 @@ bool conv_win_applicable(const ConvKernelArgs &k);
 void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s);   // shape 0: 256x128 (4x2 waves), 1: 256x64 (8x1), 2: 256x64 (4x2)
 const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
+// sampled (shader cycles, 100 MHz ticks) accumulated inside the window kernels since the last reset
+void conv_win_clock(unsigned long long *cycles_ticks, bool reset);
+void conv_win2_clock(unsigned long long *cycles_ticks, bool reset);
+void conv_win2_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING2 builds: wait, barrier, body, prologue, epilogue, total cycles, steps, waves
 void conv_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING builds: wait / barrier / body / total cycles, steps, waves
 
 }  // namespace yds

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
     char *Bs = smem16 + 2 * BM * ROWB;                     // [2][BN][ROWB]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): LDS-DMA destinations need no v_readfirstlane per piece
     const int wm = wave / WN, wn = wave % WN;
     int m0, n0;
     {
@@ -272,7 +272,7 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     extern __shared__ __attribute__((aligned(16))) char ring[];     // [NS][STAGE]
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): LDS-DMA destinations need no v_readfirstlane per piece
     const int wm = wave / WN, wn = wave % WN;
     int m0, n0;
     {

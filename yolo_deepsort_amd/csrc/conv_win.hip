@@ -23,6 +23,11 @@
 
 namespace yds {
 
+// Sustained shader clock INSIDE the kernel: one workgroup in 32 samples the shader-cycle counter (s_memtime) and the constant
+// 100 MHz counter (s_memrealtime) at its start and end; cycles / ticks is the clock the chip really ran at while every CU
+// was busy with this kernel (it is power limited: ~1.55 GHz, not the 2.4 GHz the MFMA peak is quoted at).
+__device__ unsigned long long yds_clk_win[2];
+
 namespace {
 
 constexpr int BM = 256, NW = 8, NT = NW * 64;
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     const int zoff = nbuf * WB + NSB * B_STAGE;                  // zero row
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): LDS-DMA destinations need no v_readfirstlane per piece
     const int wm = wave / WN, wn = wave % WN;
     int m0, n0;
     {
@@ -56,6 +61,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         n0 = tn * BN;
     }
     if (tid < 32) reinterpret_cast<float *>(smem + zoff)[tid] = 0.f;
+    const bool clk_sample = tid == 0 && (blockIdx.x & 31) == 0;
+    unsigned long long clk_c0 = 0, clk_w0 = 0;
+    if (clk_sample) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = wall_clock64(); }
 
     const int W = p.W, G = p.Cin / 32;
     const int drow = lane >> 3, dpos = lane & 7;
@@ -245,6 +253,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
             for (int e = 0; e < 16; ++e)
                 acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT, true>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);   // whole-tile staging
+    if (clk_sample) {
+        atomicAdd(&yds_clk_win[0], __builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(&yds_clk_win[1], wall_clock64() - clk_w0);
+    }
 }
 
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
@@ -265,6 +277,14 @@ template <int BN, int WM, int WN, int ACT, int RES, int TERMS = 3> void launch_i
 }
 
 }  // namespace
+
+void conv_win_clock(unsigned long long *cycles_ticks, bool reset) {
+    YDS_HIP(hipMemcpyFromSymbol(cycles_ticks, HIP_SYMBOL(yds_clk_win), 2 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[2] = {};
+        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_clk_win), z, sizeof z));
+    }
+}
 
 bool conv_win_applicable(const ConvKernelArgs &k) {
     if (!(k.ksize == 3 && k.stride == 1 && k.pad == 1 && k.fmt_x == FMT_H16 && k.Cin % 32 == 0 && k.H == k.Ho && k.W == k.Wo)) return false;

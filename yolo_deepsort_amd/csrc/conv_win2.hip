@@ -18,7 +18,17 @@
 #define YDS_WIN2_ORDER 1     // 1: fragments of the next step in the first MFMA slots, DMA pieces after (measured: faster on 6 of 8 shapes); 0: DMA first
 #endif
 
+#ifndef YDS_WIN2_TERM_MAJOR
+#define YDS_WIN2_TERM_MAJOR 0     // measured: term-major MFMA order is 3-5 % slower at batch 16 and equal for a lone workgroup
+#endif
+#ifndef YDS_TIMING2
+#define YDS_TIMING2 0                     // experiment: s_memtime phase accounting (conv_win2_debug_prof)
+#endif
+
 namespace yds {
+
+__device__ unsigned long long yds_prof2[8];
+__device__ unsigned long long yds_clk_win2[2];  // sustained shader clock inside the kernel: (cycles, 100 MHz ticks) of one workgroup in 32 (see conv_win.hip)    // wait, barrier, body, prologue, epilogue, total, steps, waves (YDS_TIMING2 builds)
 
 namespace {
 
@@ -30,7 +40,7 @@ constexpr int B_INST2 = BN2 / (16 * NW2);       // filter DMA instructions per w
 constexpr int MAX_WROWS2 = 384;
 
 template <int ACT, int RES, int TERMS>
-__global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, int wrows, int apw) {
+__global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, int wrows, int apw, int stagger) {
     constexpr int WM = 2, WN = 2, TM = 2, TN = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int WB = wrows * ROW2;                                 // bytes per window buffer
@@ -38,7 +48,7 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     const int zoff = 2 * WB + NSB2 * B_STAGE2;                   // zero row
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): LDS-DMA destinations need no v_readfirstlane per piece
     const int wm = wave / WN, wn = wave % WN;
     int m0, n0;
     {
@@ -48,6 +58,16 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
         n0 = tn * BN2;
     }
     if (tid < 16) reinterpret_cast<float *>(smem + zoff)[tid] = 0.f;
+    const bool clk_sample = tid == 0 && (blockIdx.x & 31) == 0;
+    unsigned long long clk_c0 = 0, clk_w0 = 0;
+    if (clk_sample) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = wall_clock64(); }
+    // Phase offset between the two workgroups of a CU: every workgroup of a launch starts at the same instant, so all of
+    // them reach their prologue (window + filters) and their epilogue (output + residual, HBM bound) TOGETHER and the matrix
+    // cores idle meanwhile - about half of a tile's time.  The second workgroup of every CU (blocks 256..511 of the first
+    // wave of dispatches) therefore starts `stagger` x 8128 cycles late; slots are refilled as they free up, so the offset
+    // carries through the whole launch and one workgroup of a CU computes while the other one moves data.
+    if (stagger && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1))
+        for (int q = 0; q < stagger; ++q) __builtin_amdgcn_s_sleep(127);
 
     const int W = p.W, G = p.Cin / 32, HG = 2 * G;               // half groups
     const int drow = lane >> 2, dpos = lane & 3;
@@ -123,16 +143,27 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
             fr[buf][f] = *reinterpret_cast<const h8 *>(bst + (lo ? b_lo : b_hi) + (which - TM) * 32 * ROW2);
         }
     };
+    // MFMA order: term-major (all hi x hi products, then hi x lo, then lo x hi).  The two cross terms of a tile accumulate
+    // into the same registers; issued back to back (tile-major order) the second one waits for the first one's result -
+    // 64 cycles of latency against 32 of issue - which a wave that has its SIMD to itself cannot hide.
     auto mfma = [&](int buf, int m) {
+#if YDS_WIN2_TERM_MAJOR
+        const int term = m / (TM * TN), ij = m % (TM * TN), i = ij / TN, j = ij % TN;
+#else
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
+#endif
         if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[buf][2 * i], al = fr[buf][2 * i + 1], bh = fr[buf][2 * (TM + j)], bl = fr[buf][2 * (TM + j) + 1];
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
         else if (term == 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[i][j], 0, 0, 0);
         else acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[i][j], 0, 0, 0);
     };
-    // fragment order: the operands of accumulator tile (0,0) first
+    // fragment order: the operands of accumulator tile (0,0) first (tile-major MFMAs) / all hi halves first (term-major)
     auto frag_order = [&](int k) {
+#if YDS_WIN2_TERM_MAJOR
+        const int order[NF] = {0, 2 * TM, 2 * TM + 2, 2, 2 * TM + 1, 2 * TM + 3, 1, 3};      // A0h B0h B1h A1h | B0l B1l | A0l A1l
+        return order[k];
+#endif
         if (k < 2) return k;                    // A0h, A0l
         if (k < 4) return 2 * TM + (k - 2);     // B0h, B0l
         if (k < 6) return 2 * TM + 2 + (k - 4); // B1h, B1l
@@ -151,6 +182,9 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
         }
     };
 
+    unsigned long long c_wait = 0, c_bar = 0, c_body = 0, c_steps = 0, c_prev = 0;
+    const unsigned long long c_start = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0;
+    const unsigned long long w_start = YDS_TIMING2 == 2 ? wall_clock64() : 0;                 // constant 100 MHz: effective shader clock = cycles / ticks
     // Step t = (hg, TAP); fragments of step t sit in fr[PAR] (read during step t-1).
     //   top      s_waitcnt vmcnt(N) + lgkmcnt(0), s_barrier: stage t+1 (fetched during step t-3) and - before a new half group -
     //            its window have landed for every wave; every wave has finished READING stage t, so its slot can be refilled
@@ -168,10 +202,13 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
         constexpr int N_OUT = !LAST || TAP <= 5 ? 2 * B_INST2 : (TAP == 6 ? B_INST2 : 0);
         const int hg1 = TAP + 1 >= 9 ? hg + 1 : hg, hg4 = TAP + 4 >= 9 ? hg + 1 : hg;
         const int slot0 = (hg + TAP) & 3;                        // ring slot of stage t: t = 9*hg + TAP, 9 = 1 mod 4
+        unsigned long long q0 = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0, q1 = q0, q2 = q0;
         if (NEXT) {
             wait_vmcnt<N_OUT>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (YDS_TIMING2) q1 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
+            if (YDS_TIMING2) q2 = __builtin_amdgcn_s_memtime();
             tap_addr(hg1, TAP1);
         }
         const char *bst1 = bring + ((slot0 + 1) & 3) * B_STAGE2;
@@ -187,6 +224,9 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
             else if (o - NDMA < NF) { if (NEXT) frag_read(bst1, PAR ^ 1, frag_order(o - NDMA)); }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // (no sample at the end of the body: it would wait for the fragment reads in flight and serialise the pipeline; the
+        //  body of step t is measured as q0 of step t+1 minus q2 of step t)
+        if (YDS_TIMING2 && NEXT) { c_wait += q1 - q0; c_bar += q2 - q1; if (c_prev) c_body += q0 - c_prev; c_prev = q2; ++c_steps; }
     };
     // nine taps of one half group; the step parity alternates and 9 is odd, so half groups alternate between two bodies
     auto half_group = [&](int hg, auto last_c, auto par_c) {
@@ -215,6 +255,7 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     for (int f = 0; f < NF; ++f) frag_read(bring, 0, f);
     __builtin_amdgcn_sched_barrier(0);
 
+    const unsigned long long c_loop = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0;
     // half groups 0 .. HG-1: parity of the first step of half group hg is hg & 1 (9 steps each); HG is even
     for (int hg = 0; hg + 2 < HG; hg += 2) {
         half_group(hg, std::false_type{}, std::integral_constant<int, 0>{});
@@ -223,6 +264,7 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     half_group(HG - 2, std::false_type{}, std::integral_constant<int, 0>{});
     half_group(HG - 1, std::true_type{}, std::integral_constant<int, 1>{});
 
+    const unsigned long long c_end = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads();                                            // every wave is done with the windows and the ring
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -232,6 +274,19 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
             for (int e = 0; e < 16; ++e)
                 acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     conv_epilogue<BM2, BN2, WM, WN, ACT, RES, TM, TN, NT2, true>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);   // whole-tile staging
+    if (clk_sample) {
+        atomicAdd(&yds_clk_win2[0], __builtin_amdgcn_s_memtime() - clk_c0);
+        atomicAdd(&yds_clk_win2[1], wall_clock64() - clk_w0);
+    }
+    if (YDS_TIMING2) {
+        __syncthreads();
+        if (tid == 0 && (blockIdx.x & 15) == 0) {                // a sample of the workgroups: same-address atomics of every wave would dominate the launch
+            const unsigned long long c_fin = __builtin_amdgcn_s_memtime();
+            atomicAdd(&yds_prof2[0], YDS_TIMING2 == 2 ? wall_clock64() - w_start : c_wait); atomicAdd(&yds_prof2[1], c_bar); atomicAdd(&yds_prof2[2], c_body);
+            atomicAdd(&yds_prof2[3], c_loop - c_start); atomicAdd(&yds_prof2[4], c_fin - c_end); atomicAdd(&yds_prof2[5], c_fin - c_start);
+            atomicAdd(&yds_prof2[6], c_steps); atomicAdd(&yds_prof2[7], 1ull);
+        }
+    }
 }
 
 int window_rows2(int W) { return (BM2 + 2 * W + 2 + 15) / 16 * 16; }
@@ -247,7 +302,9 @@ template <int ACT, int RES, int TERMS = 3> void launch_inst_win2(ConvKernelArgs 
         attr_set = smem;
     }
     dim3 grid(plan_tile_map(k, BM2, BN2));
-    hipLaunchKernelGGL(kern, grid, dim3(NT2), smem, s, k, wrows, apw);
+    static const int stagger_env = getenv("YDS_WIN2_STAGGER") ? atoi(getenv("YDS_WIN2_STAGGER")) : -1;
+    const int stagger = stagger_env >= 0 ? stagger_env : 0;
+    hipLaunchKernelGGL(kern, grid, dim3(NT2), smem, s, k, wrows, apw, stagger);
     YDS_HIP(hipGetLastError());
 }
 
@@ -258,6 +315,22 @@ bool conv_win2_applicable(const ConvKernelArgs &k) {
     const int wrows = window_rows2(k.W);
     if (wrows > MAX_WROWS2) return false;                        // two resident workgroups: <= 80 KB each; <= 6 window pieces per wave and half group
     return (size_t)k.M * ((size_t)k.ldx / 4) < (1ull << 32) && (size_t)k.Cout * (k.Kpad / 4) < (1ull << 32);
+}
+
+void conv_win2_clock(unsigned long long *cycles_ticks, bool reset) {
+    YDS_HIP(hipMemcpyFromSymbol(cycles_ticks, HIP_SYMBOL(yds_clk_win2), 2 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[2] = {};
+        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_clk_win2), z, sizeof z));
+    }
+}
+
+void conv_win2_debug_prof(unsigned long long *out, bool reset) {
+    YDS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(yds_prof2), sizeof(unsigned long long) * 8));
+    if (reset) {
+        unsigned long long z[8] = {};
+        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_prof2), z, sizeof(z)));
+    }
 }
 
 void launch_conv_win2(ConvKernelArgs k, hipStream_t s) {

@@ -892,10 +892,22 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st);
     YDS_API_END
 }
+int yds_conv_clock(double *ghz, double *sampled_ms, int reset) {
+    YDS_API_BEGIN
+    YDS_HIP(hipDeviceSynchronize());
+    unsigned long long a[2], b[2];
+    yds::conv_win_clock(a, reset != 0);
+    yds::conv_win2_clock(b, reset != 0);
+    const double cycles = (double)a[0] + (double)b[0], ticks = (double)a[1] + (double)b[1];
+    if (ghz) *ghz = ticks > 0 ? cycles / ticks * 0.1 : 0.0;              // ticks are 10 ns
+    if (sampled_ms) *sampled_ms = ticks * 1e-5;
+    YDS_API_END
+}
 int yds_debug_prof(uint64_t *out8, int reset) {
     YDS_API_BEGIN
     unsigned long long v[8];
-    yds::conv_debug_prof(v, reset != 0);
+    if (reset & 2) yds::conv_win2_debug_prof(v, (reset & 1) != 0);      // bit 1: the two-workgroup window kernel's counters
+    else yds::conv_debug_prof(v, reset != 0);
     for (int i = 0; i < 8; ++i) out8[i] = v[i];
     YDS_API_END
 }

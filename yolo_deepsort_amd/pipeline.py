@@ -76,6 +76,13 @@ def conv_timing(net, mode=0):
             for v in range(nv)]
 
 
+def conv_clock(reset=True):
+    """(GHz, sampled ms): the shader clock sustained inside the window-resident conv kernels since the last reset."""
+    ghz, ms = C.c_double(0), C.c_double(0)
+    _lib.check(_lib.load().yds_conv_clock(C.byref(ghz), C.byref(ms), 1 if reset else 0))
+    return ghz.value, ms.value
+
+
 def load_injection_sets(net, sets, logit=6.0):
     """sets: list (per step) of lists (per batch slot) of [n,9] arrays."""
     bm = net.batch_max
