@@ -154,3 +154,61 @@ def test_masked_rank_takes_its_only_visible_device():
     code = ("import sys; sys.path.insert(0, %r)\nfrom yolo_deepsort_amd import _lib\nprint('BOUND', _lib.init(), _lib.pci_bus_id())\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LOCAL_RANK="3", HIP_VISIBLE_DEVICES="0"), capture_output=True, text=True, timeout=300)
     assert "BOUND 0" in out.stdout, out.stdout + out.stderr
+
+
+SINGLE_STREAM = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from yolo_deepsort_amd import _lib, cfgs, synth
+from yolo_deepsort_amd.dist import Ranks
+from yolo_deepsort_amd.models import Darknet
+from yolo_deepsort_amd.detect import ImageDetector
+from yolo_deepsort_amd.deep_sort import DeepSort
+from yolo_deepsort_amd.single_stream import SingleStream
+ranks = Ranks(os.environ.get("YDS_DIST_BACKEND", "nccl"))
+_lib.init()
+ranks.connect()
+cfg = cfgs.cfg_text("yolov3-tiny", 416, 416)
+net = Darknet(None, img_size=(416, 416), cfg_text=cfg)
+net.load_darknet_weights(None, blob=synth.darknet_weights_blob(cfg, 0, 1.0))
+names = %(names)r
+det = ImageDetector(net, names, thres=0.5, nms_thres=0.4)
+ds = DeepSort(synth.reid_state_dict(0), use_cuda=True, max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
+scene = synth.PersonScene(6, frame_hw=(270, 480), seed=3, occlude_frac=0.0)
+frames = [scene.frame(t) for t in range(9)]
+out = SingleStream.from_components(ranks, det, ds, class_mask=[0, 2, 4]).run(frames)
+if ranks.rank == 0:
+    arrays = {f"f{t}": (np.full((1, 6), -1, np.int32) if o is None else np.asarray(o, np.int32).reshape(-1, 6)) for t, o in enumerate(out)}
+    np.savez(%(dump)r, **arrays)
+    print("OK", len(out))
+ranks.shutdown()
+'''
+
+
+def test_single_stream_mode_two_ranks_equals_one_process(tmp_path):
+    """SURVEY 8e optional mode: ONE stream, frames detected + embedded round-robin on two ranks (both on GPU 0 here, gloo
+    transport), fixed-size (tlwh, payload, feats) blocks all-gathered, tracker on rank 0 in frame order - the rows must equal
+    the same script run as a single rank (which is the plain frame-by-frame loop)."""
+    import numpy as np
+    from yolo_deepsort_amd import cfgs
+    names = str(tmp_path / "coco.names")
+    open(names, "w").write(cfgs.coco_names_text())
+    res = {}
+    for world in (2, 1):
+        dump = str(tmp_path / f"rows{world}.npz")
+        script = tmp_path / f"run{world}.py"
+        script.write_text(SINGLE_STREAM % dict(root=ROOT, names=names, dump=dump))
+        env = dict(os.environ, YDS_DEVICE="0", YDS_DIST_BACKEND="gloo")
+        if world == 2:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29581", str(script)]
+        else:
+            cmd = [sys.executable, str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0 and "OK 9" in out.stdout, out.stdout[-800:] + out.stderr[-2000:]
+        res[world] = np.load(dump)
+    rows = 0
+    for t in range(9):
+        assert np.array_equal(res[2][f"f{t}"], res[1][f"f{t}"]), t
+        rows += int((res[1][f"f{t}"][:, 4] >= 0).sum())
+    assert rows > 0

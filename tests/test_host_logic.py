@@ -422,3 +422,50 @@ def test_action_module_matches_committed_reference_fixture(monkeypatch):
         got = [[int(a), int(b), str(c)] for a, b, c in B.update(det)]
         assert got == want["frames"][t], t
     assert (B.update(None) is None) == want["none_returns_none"]
+
+
+def test_single_stream_mode_two_ranks_gloo():
+    """SURVEY 8e optional mode on CPU (gloo, world 2): frames are 'detected' round-robin, exchanged as fixed-size blocks and
+    'tracked' in frame order on rank 0 - with stand-in detect / track callables that make order and content checkable."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from yolo_deepsort_amd.dist import Ranks
+from yolo_deepsort_amd import single_stream as ss
+r = Ranks("gloo")
+frames = list(range(7))                                       # 7 frames on 2 ranks: the last round is ragged
+def detect(f):
+    if f == 3:
+        return None                                           # detector returned None: the tracker must not be called
+    d = f %% 4                                                # 0 detections at f = 4: the tracker IS called with D = 0
+    rng = np.random.RandomState(f)
+    return rng.rand(d, 4).astype(np.float32), np.full(d, f, np.float32), rng.rand(d, 512).astype(np.float32)
+seen = []
+def track(tlwh, payload, feats):
+    seen.append((tlwh.shape, payload.tolist(), float(feats.sum())))
+    return ("rows", len(tlwh))
+out = ss.SingleStream(r, detect, track).run(frames)
+if r.rank == 0:
+    assert len(out) == 7 and out[3] is None and out[4] == ("rows", 0) and out[6] == ("rows", 2)
+    want = [detect(f) for f in frames if f != 3]
+    assert len(seen) == 6
+    for (shape, pay, fs), w in zip(seen, want):               # in frame order, bit-identical content
+        assert shape == w[0].shape and pay == w[1].tolist() and abs(fs - float(w[2].sum())) < 1e-3
+    print("OK")
+else:
+    assert out == [] and seen == []
+r.shutdown()
+''' % ROOT
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(code)
+    try:
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                              "--master-port", "29543", f.name], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543"))
+    finally:
+        os.unlink(f.name)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
+    from yolo_deepsort_amd import single_stream as ss
+    with pytest.raises(ValueError):
+        ss.pack_frame(np.zeros((151, 4), np.float32), np.zeros(151), np.zeros((151, 512)))

@@ -122,6 +122,24 @@ class Ranks:
             allb = np.stack([p.numpy() for p in parts], 0)
         return [unpack_rows(allb[r]) for r in range(self.world)]
 
+    def gather_array(self, arr):
+        """All-gather of one fixed-size numpy array per rank: [world, *arr.shape] on every rank (RCCL through yds_comm_allgather,
+        or the host group)."""
+        arr = np.ascontiguousarray(arr)
+        if self.world == 1:
+            return arr[None].copy()
+        out = np.zeros((self.world,) + arr.shape, arr.dtype)
+        if self.comm is not None:
+            from . import _lib
+            _lib.check(_lib.load().yds_comm_allgather(self.comm, _lib.ptr(arr), arr.nbytes, _lib.ptr(out)))
+        else:
+            import torch
+            flat = torch.from_numpy(arr.reshape(-1).view(np.uint8).copy())
+            parts = [torch.zeros_like(flat) for _ in range(self.world)]
+            self.dist.all_gather(parts, flat)
+            out = np.stack([p.numpy().view(arr.dtype).reshape(arr.shape) for p in parts], 0)
+        return out
+
     def gather_objects(self, obj):
         """[obj of rank 0, obj of rank 1, ...] on every rank (small host objects: device ids, per-rank rates)."""
         if self.dist is None:
