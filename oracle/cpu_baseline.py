@@ -62,10 +62,14 @@ def main():
     except Exception:
         pass
     n_threads = os.cpu_count() if args.plain else threads()
-    print(json.dumps(dict(value=round(args.frames / dt, 4), unit="frames/s", cores=int(n_threads), kind="port",
+    # `cores` = the threads the dominant stage (the BLAS GEMMs of the convolutions) really ran on: this numpy's BLAS caps its pool
+    # (64 on the 256-thread bench host), the OpenMP stages around it use `openmp_threads`
+    print(json.dumps(dict(value=round(args.frames / dt, 4), unit="frames/s", cores=int(blas or n_threads), kind="port",
                           sample=f"first {args.frames} frames of the same stream through oracle/ "
-                                 f"({'numpy' if args.plain else 'C + OpenMP gather/epilogue/pool'}, BLAS sgemm on {blas} threads; {dt:.1f} s)",
-                          seconds=round(dt, 2), tracker_rows=int(rows), host_cpus=os.cpu_count())))
+                                 f"({'numpy' if args.plain else 'C + OpenMP gather/epilogue/pool'} on {n_threads} threads, BLAS sgemm on {blas} "
+                                 f"of {os.cpu_count()} host threads; {dt:.1f} s)",
+                          seconds=round(dt, 2), tracker_rows=int(rows), host_cpus=os.cpu_count(), openmp_threads=int(n_threads),
+                          blas_threads=blas)))
 
 
 if __name__ == "__main__":

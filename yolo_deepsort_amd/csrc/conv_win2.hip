@@ -18,6 +18,9 @@
 #define YDS_WIN2_ORDER 1     // 1: fragments of the next step in the first MFMA slots, DMA pieces after (measured: faster on 6 of 8 shapes); 0: DMA first
 #endif
 
+#ifndef YDS_WIN2_SKEW
+#define YDS_WIN2_SKEW 0     // measured: the skewed step (last MFMAs of step t-1 issued after the barrier of step t) is no faster, 3-8 % slower for a lone workgroup
+#endif
 #ifndef YDS_WIN2_TERM_MAJOR
 #define YDS_WIN2_TERM_MAJOR 0     // measured: term-major MFMA order is 3-5 % slower at batch 16 and equal for a lone workgroup
 #endif
@@ -213,17 +216,49 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
         }
         const char *bst1 = bring + ((slot0 + 1) & 3) * B_STAGE2;
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int NDMA = 1 + B_INST2;
+#if YDS_WIN2_SKEW
+        // Skewed step: the last SKEW MFMAs of step t-1 are issued AFTER this step's barrier, under the DMA pieces, and the
+        // remaining MFMAs of step t carry the fragment reads of step t+1.  The matrix pipe then still holds work while the
+        // wave waits at the top of the step (fragments, barrier) - with one MFMA-issuing wave per SIMD it used to drain there.
+        constexpr int SKEW = 3;                                 // tile (1,1): fragments A1h, A1l, B1h, B1l
+        if (TAP != 0 || hg != 0) {
+#pragma unroll
+            for (int m = NM - SKEW; m < NM; ++m) {
+                mfma(PAR ^ 1, m);
+                __builtin_amdgcn_sched_barrier(0);
+                const int o = m - (NM - SKEW);
+                if (o == 0) { if (!LAST && TAP < 6 && TAP < apw) a_piece(hg + 1, TAP); }
+                else if (o - 1 < B_INST2) { if (REFILL) b_piece(hg4, TAP4, slot0, o - 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            if (!LAST && TAP < 6 && TAP < apw) a_piece(hg + 1, TAP);
+#pragma unroll
+            for (int b = 0; b < B_INST2; ++b) if (REFILL) b_piece(hg4, TAP4, slot0, b);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM - SKEW; ++m) {
+            mfma(PAR, m);
+            __builtin_amdgcn_sched_barrier(0);
+            // fragments whose registers the skewed MFMAs above read are re-filled last
+            const int order[NF] = {0, 1, 2 * TM, 2 * TM + 1, 2, 3, 2 * TM + 2, 2 * TM + 3};
+            if (m < NF && NEXT) frag_read(bst1, PAR ^ 1, order[m]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             mfma(PAR, m);
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int NDMA = 1 + B_INST2;
             const int o = YDS_WIN2_ORDER == 0 ? m : (m < NF ? m + NDMA : (m - NF < NDMA ? m - NF : NDMA + NF));   // operation: 0 window, 1..2 filter, 3..10 fragments
             if (o == 0) { if (!LAST && TAP < 6 && TAP < apw) a_piece(hg + 1, TAP); }
             else if (o - 1 < B_INST2) { if (REFILL) b_piece(hg4, TAP4, slot0, o - 1); }
             else if (o - NDMA < NF) { if (NEXT) frag_read(bst1, PAR ^ 1, frag_order(o - NDMA)); }
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         // (no sample at the end of the body: it would wait for the fragment reads in flight and serialise the pipeline; the
         //  body of step t is measured as q0 of step t+1 minus q2 of step t)
         if (YDS_TIMING2 && NEXT) { c_wait += q1 - q0; c_bar += q2 - q1; if (c_prev) c_body += q0 - c_prev; c_prev = q2; ++c_steps; }
@@ -264,6 +299,10 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     half_group(HG - 2, std::false_type{}, std::integral_constant<int, 0>{});
     half_group(HG - 1, std::true_type{}, std::integral_constant<int, 1>{});
 
+#if YDS_WIN2_SKEW
+#pragma unroll
+    for (int m = NM - 3; m < NM; ++m) mfma(1, m);               // the skewed MFMAs of the last step (its fragments sit in fr[1])
+#endif
     const unsigned long long c_end = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads();                                            // every wave is done with the windows and the ring
 #pragma unroll

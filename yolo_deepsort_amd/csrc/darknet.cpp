@@ -851,8 +851,11 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     std::vector<float> hx((size_t)n * h * w * cin), hw((size_t)cout * kpad), hb(cout);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.f - 1.f; };
-    for (auto &v : hx) v = rnd();
-    for (auto &v : hw) v = rnd() * 0.05f;
+    // YDS_BENCH_DATA=zero | const: power experiment (the chip is power limited: operands that do not toggle run at a higher clock)
+    const char *dk = getenv("YDS_BENCH_DATA");
+    const int data_kind = !dk ? 0 : (!strcmp(dk, "zero") ? 1 : (!strcmp(dk, "const") ? 2 : 0));
+    for (auto &v : hx) v = data_kind == 1 ? 0.f : data_kind == 2 ? 0.5f : rnd();
+    for (auto &v : hw) v = data_kind == 1 ? 0.f : data_kind == 2 ? 0.03125f : rnd() * 0.05f;
     for (auto &v : hb) v = rnd();
     DevBuf<float> x, wt, b, y((size_t)n * ho * wo * ldy), r((size_t)n * ho * wo * ldy);
     DevBuf<uint16_t> wt16;
