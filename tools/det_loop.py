@@ -6,7 +6,7 @@ from yolo_deepsort_amd import _lib, cfgs, synth
 from yolo_deepsort_amd.models import Darknet
 _lib.init(0); lib=_lib.load()
 B=int(os.environ.get("DET_LOOP_B", "16"))
-cfg=cfgs.cfg_text("yolov3",608,608)
+cfg=cfgs.cfg_text(os.environ.get("DET_NET", "yolov3"),608,608)
 net=Darknet(None,img_size=(608,608),batch_max=B,cfg_text=cfg); net.load_darknet_weights(None,blob=synth.darknet_weights_blob(cfg,0))
 frames=np.random.RandomState(0).randint(0,256,(B,1080,1920,3)).astype(np.uint8)
 dev=_lib.DeviceBuffer.from_array(frames)

@@ -93,6 +93,10 @@ struct ConvArgs {
     int ksize = 1, stride = 1, pad = 0, kpad = 0;
     int act = ACT_LINEAR, res_mode = RES_NONE;
     int terms = 3;         // f16x3 kernels: 3 = split-fp16 (fp32-class), 1 = single-term fp16 operands ("half" mode of a detector)
+    // merged launch of two convolutions that read the same tensor (CSP split of yolov4): y.c = both filter counts, filters
+    // [n_split, y.c) are written to y2 (same pixels, own stride / channel offset); w / w16 / bias hold both filter sets
+    View y2;
+    int n_split = 0;
 };
 // returns the tile-variant id that was launched (see conv_variant_name)
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice

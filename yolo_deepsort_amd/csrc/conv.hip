@@ -234,6 +234,12 @@ ConvKernelArgs make_conv_args(const ConvArgs &a) {
     k.act = a.act; k.res_mode = a.res.p ? a.res_mode : RES_NONE;
     k.fmt_x = a.x.fmt; k.fmt_y = a.y.fmt; k.fmt_r = a.res.p ? a.res.fmt : FMT_F32;
     k.terms = a.terms == 1 ? 1 : 3;
+    if (a.n_split > 0) {
+        if (a.n_split % 4 || a.n_split >= a.y.c || !a.y2.p || a.y2.fmt != a.y.fmt || a.y2.ld % 4 || ((uintptr_t)a.y2.p & 15) || a.res.p)
+            fail("conv: bad merged-launch description (n_split %d of %d filters)", a.n_split, a.y.c);
+        if (a.y.fmt == FMT_H16 && (a.n_split % 32 || (a.y.c - a.n_split) % 32 || a.y2.ld % 32 || ((uintptr_t)a.y2.p & 127))) fail("conv: merged H16 outputs need 32-channel granularity");
+        k.y2 = a.y2.p; k.ldy2 = a.y2.ld; k.n_split = a.n_split;
+    }
     if (a.x.fmt == FMT_H16 && (a.x.c % 32 || a.x.ld % 32 || ((uintptr_t)a.x.p & 127))) fail("conv: H16 input needs 32-channel granularity");
     if (a.y.fmt == FMT_H16 && (a.y.c % 32 || a.y.ld % 32 || ((uintptr_t)a.y.p & 127))) fail("conv: H16 output needs 32-channel granularity");
     if (a.x.c % 4 || a.x.ld % 4 || ((uintptr_t)a.x.p & 15)) fail("conv: input channels/stride must be multiples of 4 (got c=%d ld=%d)", a.x.c, a.x.ld);
@@ -349,8 +355,8 @@ static std::string tune_key(const ConvArgs &a) {
         while (p2 * 2 <= n) p2 *= 2;
         n = n >= p2 + p2 / 2 ? p2 + p2 / 2 : p2;
     }
-    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d", conv_math() + (a.terms == 1 ? 10 : 0), n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
-             a.y.h, a.y.w, a.ksize, a.stride, a.act, a.res.p ? a.res_mode : 0, a.x.fmt, a.y.fmt);
+    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d_sp%d", conv_math() + (a.terms == 1 ? 10 : 0), n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
+             a.y.h, a.y.w, a.ksize, a.stride, a.act, a.res.p ? a.res_mode : 0, a.x.fmt, a.y.fmt, a.n_split);
     return buf;
 }
 
@@ -366,7 +372,7 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
         if (f16v && f16_variant_is_win2(v - kF32Variants) && !conv_win2_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (!(presplit && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
-    if (conv_math() == MATH_F16X3 && a.w16 && a.terms != 1 && conv_splitk_preferred(make_conv_args(a))) return kF32Variants + 14;   // by rule (see there)
+    if (conv_math() == MATH_F16X3 && a.w16 && a.terms != 1 && a.n_split == 0 && conv_splitk_preferred(make_conv_args(a))) return kF32Variants + 14;   // by rule (see there)
     const std::string key = tune_key(a);
     auto &cache = tune_cache();
     auto it = cache.find(key);
@@ -388,7 +394,7 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
     std::vector<int> cand;
     for (int v = v_lo; v <= v_hi; ++v) {
         if (v == v_hi) {                                 // last candidate: the direct first-layer kernel
-            if (!direct_ok) break;
+            if (!direct_ok || a.n_split) break;
             v = kDirectVariant;
         }
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers

@@ -31,6 +31,9 @@ struct ConvKernelArgs {
     int fmt_x, fmt_y, fmt_r;              // TensorFmt of input, output and residual views
     int terms;                            // 3: f16x3, 1: hi halves only (half mode; LDS-DMA and window kernels)
     int ksplit = 1;                       // LDS-DMA kernel: K ranges (grid.y); > 1 writes raw partial sums into slab blockIdx.y of y
+    // two convolutions of the same input in one launch (CSP split, darknet.cpp): filters [n_split, Cout) write to y2
+    float *y2 = nullptr;
+    int ldy2 = 0, n_split = 0;
     // XCD-aware tile map: the 8 XCDs own an xm x xn grid of rectangles of rm x rn tiles (workgroup id % 8 = XCD)
     int tiles_m, tiles_n, xm, rm, rn;
 };
@@ -106,6 +109,10 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
     const int c4 = tid % C4, rr = tid / C4;
     const int n = n0 + c4 * 4;
     const bool n_vec = n + 3 < p.Cout;
+    // output destination of this thread's four channels (merged launches: the second convolution's filters go to y2)
+    const bool second = p.n_split > 0 && n >= p.n_split;
+    float *const y_base = second ? p.y2 : p.y;
+    const int y_ld = second ? p.ldy2 : p.ldy, ny = second ? n - p.n_split : n;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n_vec) bias4 = *reinterpret_cast<const float4 *>(p.bias + n);
     else {
@@ -179,7 +186,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
                     o[k] = apply_act<ACT>(o[k]);
                     if (RES == RES_AFTER_ACT) o[k] += rs[k];
                 }
-                float *yp = p.y + (size_t)m * p.ldy;
+                float *yp = y_base + (size_t)m * y_ld;
                 if (YH) {
                     // neighbouring lanes hold neighbouring channel quads of the same pixel: they trade halves so that each lane
                     // issues ONE 16-byte store (even lane: 8 hi halves, odd lane: 8 lo halves) instead of two 8-byte ones.
@@ -194,12 +201,12 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
                     union { h16x4 h[2]; float4 f; } out;
                     out.h[0] = odd ? recv.h : hi;
                     out.h[1] = odd ? lo : recv.h;
-                    const int nq = n & ~7;                                          // first channel of the lane pair
+                    const int nq = ny & ~7;                                         // first channel of the lane pair
                     char *g = reinterpret_cast<char *>(yp + (nq & ~31)) + (nq & 31) * 2 + (odd ? 64 : 0);
                     if (live) *reinterpret_cast<float4 *>(g) = out.f;
                 } else if (live) {
-                    if (n_vec) *reinterpret_cast<float4 *>(yp + n) = make_float4(o[0], o[1], o[2], o[3]);
-                    else { yp[n] = o[0]; if (n + 1 < p.Cout) yp[n + 1] = o[1]; if (n + 2 < p.Cout) yp[n + 2] = o[2]; }
+                    if (n_vec) *reinterpret_cast<float4 *>(yp + ny) = make_float4(o[0], o[1], o[2], o[3]);
+                    else { yp[ny] = o[0]; if (n + 1 < p.Cout) yp[ny + 1] = o[1]; if (n + 2 < p.Cout) yp[ny + 2] = o[2]; }
                 }
             }
             if (!ONE_PASS && pass + 1 < WM) __syncthreads();

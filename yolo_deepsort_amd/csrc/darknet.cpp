@@ -267,6 +267,25 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
         storage[i].fmt = (h16_ok[i] && storage[i].ld % 32 == 0) ? FMT_H16 : FMT_F32;
         storage[i].owns = true;
     }
+    // ---- pass 5: CSP splits.  conv a (1x1) / route to a's input / conv b (1x1): both read the same tensor; one launch
+    //      with the filters of both (a's first) writes a's channels to a's view and b's to b's view.
+    static const bool no_merge = getenv("YDS_NO_CSP_MERGE") != nullptr;
+    for (int i = 1; i + 2 < L && !no_merge; ++i) {
+        Layer &a = layers[i];
+        const Layer &r = layers[i + 1];
+        Layer &b = layers[i + 2];
+        if (a.type != "convolutional" || b.type != "convolutional" || r.type != "route" || r.refs.size() != 1 || r.groups) continue;
+        if (a.src < 0 || r.refs[0] != a.src || b.src != i + 1) continue;
+        if (a.ksize != 1 || b.ksize != 1 || a.stride != 1 || b.stride != 1 || a.act != b.act || a.fused_res >= 0 || b.fused_res >= 0) continue;
+        if (a.merged_into >= 0 || a.merge_next >= 0 || a.cin != b.cin) continue;
+        if ((int)i == block1_at || (int)i + 2 == block1_at || i + 2 == (int)block1_at + 1) continue;      // (the fused first block keeps its own kernel)
+        int oa = 0, ob = 0;
+        const int sa = owner_of(i, oa), sb = owner_of(i + 2, ob);
+        if (storage[sa].fmt != storage[sb].fmt || a.c % 4 || b.c % 4) continue;
+        if (storage[sa].fmt == FMT_H16 && (a.c % 32 || b.c % 32)) continue;
+        a.merge_next = i + 2;
+        b.merged_into = i;
+    }
     allocate_buffers();
 }
 
@@ -399,6 +418,22 @@ void Darknet::load_weights(const void *blob, size_t nbytes, int cutoff) {
         YDS_HIP(hipStreamSynchronize(stream));
         l.loaded = true;
     }
+    // concatenated filter sets of the CSP splits (device-to-device: [a's filters ; b's filters], same K)
+    for (int i = 0; i < (int)layers.size(); ++i) {
+        Layer &a = layers[i];
+        if (a.merge_next < 0) continue;
+        Layer &b = layers[a.merge_next];
+        if (!a.loaded || !b.loaded || a.kpad != b.kpad) { a.merge_next = -1; b.merged_into = -1; continue; }
+        const size_t na = (size_t)a.c * a.kpad, nb = (size_t)b.c * b.kpad;
+        a.wt_m.alloc(na + nb); a.wt16_m.alloc(2 * (na + nb)); a.bias_m.alloc((size_t)a.c + b.c);
+        YDS_HIP(hipMemcpyAsync(a.wt_m.p, a.wt.p, na * 4, hipMemcpyDeviceToDevice, stream));
+        YDS_HIP(hipMemcpyAsync(a.wt_m.p + na, b.wt.p, nb * 4, hipMemcpyDeviceToDevice, stream));
+        YDS_HIP(hipMemcpyAsync(a.wt16_m.p, a.wt16.p, na * 4, hipMemcpyDeviceToDevice, stream));
+        YDS_HIP(hipMemcpyAsync(a.wt16_m.p + 2 * na, b.wt16.p, nb * 4, hipMemcpyDeviceToDevice, stream));
+        YDS_HIP(hipMemcpyAsync(a.bias_m.p, a.bias.p, (size_t)a.c * 4, hipMemcpyDeviceToDevice, stream));
+        YDS_HIP(hipMemcpyAsync(a.bias_m.p + a.c, b.bias.p, (size_t)b.c * 4, hipMemcpyDeviceToDevice, stream));
+        YDS_HIP(hipStreamSynchronize(stream));
+    }
     weights_loaded = true;
 }
 
@@ -416,13 +451,25 @@ ConvArgs Darknet::conv_args(int i, int batch) const {
     return a;
 }
 
+ConvArgs Darknet::merged_conv_args(int i, int batch) const {
+    const Layer &l = layers[i];
+    ConvArgs a = conv_args(i, batch);
+    const ConvArgs b = conv_args(l.merge_next, batch);
+    a.y2 = b.y;
+    a.n_split = a.y.c;
+    a.y.c = a.y.c + b.y.c;                                       // (pointer, stride and format stay those of the first output)
+    a.w = l.wt_m.p; a.w16 = l.wt16_m.p; a.bias = l.bias_m.p;
+    return a;
+}
+
 void Darknet::autotune(int batch) {
     static const bool off = getenv("YDS_NO_AUTOTUNE") != nullptr;
     for (int i = 0; i < (int)layers.size(); ++i) {
         Layer &l = layers[i];
         const int mode = conv_math() + (half_mode ? 10 : 0);
         if (l.type != "convolutional" || !l.loaded || (l.tuned_batch == batch && l.tuned_math == mode)) continue;
-        l.variant = off ? -1 : conv_autotune(conv_args(i, batch), stream, nullptr);
+        if (l.merged_into >= 0 && layers[l.merged_into].wt_m.p) { l.tuned_batch = batch; l.tuned_math = mode; continue; }   // launched by its partner
+        l.variant = off ? -1 : conv_autotune(l.merge_next >= 0 && l.wt_m.p ? merged_conv_args(i, batch) : conv_args(i, batch), stream, nullptr);
         l.tuned_batch = batch;
         l.tuned_math = mode;
     }
@@ -473,7 +520,8 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
         Layer &l = layers[i];
         if (l.type == "convolutional") {
             if (!l.loaded) fail("forward: layer %d has no weights (call load_darknet_weights)", i);
-            ConvArgs a = conv_args(i, batch);
+            if (l.merged_into >= 0 && layers[l.merged_into].wt_m.p) continue;   // computed by the first convolution of the CSP split
+            ConvArgs a = l.merge_next >= 0 && l.wt_m.p ? merged_conv_args(i, batch) : conv_args(i, batch);
             if (i == 0 && stem_fused(batch)) continue;              // computed inside layer 1's launch
             if (i == block1_at && block1_fused(batch)) continue;    // computed inside the next layer's launch
             ConvTimeRec rec;

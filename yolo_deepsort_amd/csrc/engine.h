@@ -31,6 +31,12 @@ struct Layer {
     bool loaded = false;
     DevBuf<float> wt, bias;
     DevBuf<uint16_t> wt16;                // split-fp16 copy of wt for the f16x3 kernel
+    // CSP split (yolov4: conv 1x1, route -2, conv 1x1 - two convolutions of the same tensor): the first one launches both
+    // (merge_next = the second conv, which is skipped: merged_into = the first) from concatenated filters, so the shared
+    // input is read from HBM once
+    int merge_next = -1, merged_into = -1;
+    DevBuf<float> wt_m, bias_m;
+    DevBuf<uint16_t> wt16_m;
     // shortcut / route / pool
     bool fused = false, zero_br = false;
     int groups = 0, group_id = 0;
@@ -72,6 +78,7 @@ public:
     size_t weight_floats() const;
     View view(int layer, int batch) const;
     ConvArgs conv_args(int layer, int batch) const;
+    ConvArgs merged_conv_args(int layer, int batch) const;     // both convolutions of a CSP split in one launch
     View input_view(int batch) const;
 
     int img_h, img_w, batch_max, in_channels = 3;
