@@ -56,14 +56,14 @@ def timed_steps(wl, ranks, sync, K, W, first, host_frames, lookahead=True, keep=
     """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks.
     Every step ends with the exchange step of the multi-GPU run: the all-gather of this batch's result rows (no-op for one rank)."""
     for i in range(first, first + W):
-        wl.step(i, prefetch=lookahead and i + 1 < first + W, host_frames=host_frames)   # nothing of the timed region is enqueued before the clock starts
+        wl.step(i, prefetch=lookahead and i + 1 < first + W, host_frames=host_frames, prefetch2=i + 2 < first + W)   # nothing of the timed region is enqueued before the clock starts
     sync()
     ranks.barrier()
     sync()
     t0 = time.perf_counter()
     n_out = 0
     for i in range(first + W, first + W + K):
-        outs = wl.step(i, prefetch=lookahead and i + 1 < first + W + K, host_frames=host_frames)   # exactly K detector passes inside the timed region
+        outs = wl.step(i, prefetch=lookahead and i + 1 < first + W + K, host_frames=host_frames, prefetch2=i + 2 < first + W + K)   # exactly K detector passes (and K uploads) inside the timed region
         streams = ranks.gather_rows(outs)
         n_out += sum(0 if o is None else len(o) for st in streams for o in st)
         if keep is not None:
@@ -297,7 +297,7 @@ def main():
                        "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices]},
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_with_upload is the PCIe-inclusive rate",
             "value_with_upload": None if dt_up is None else round(frames_total / dt_up, 2),
-            "value_with_upload_note": "same K steps, frames handed over as pinned host memory and uploaded inside the step (copy stream, double buffered)",
+            "value_with_upload_note": "same K steps, frames handed over as pinned host memory and uploaded inside the timed region (copy stream, three staging buffers, each batch announced two steps ahead like a decoder queue)",
             "value_f32_math": None if f32_fps is None else round(f32_fps, 2),
             "value_frame_by_frame": None if fbf is None else round(fbf, 2),
             "value_frame_by_frame_lookahead1": None if fbf_ahead is None else round(fbf_ahead, 2),

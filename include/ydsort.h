@@ -227,6 +227,12 @@ int yds_pipeline_step(yds_pipe *, const uint8_t *frames_dev, const uint8_t *next
  * gives asynchronous full-rate copies; pageable memory works, slower. */
 int yds_pipeline_step_host(yds_pipe *, const uint8_t *frames_host, const uint8_t *next_frames_host, int h, int w,
                            int batch, int32_t *out6_host, int cap, int32_t *counts_host);
+/* Starts the upload of a batch the caller will hand to yds_pipeline_step_host LATER (as `next_frames_host` of the following call
+ * or as `frames_host` of the one after): the detector stream runs a whole pass ahead of the host, so a copy that only starts
+ * when a batch becomes `next` arrives ~1.7 ms late per 100 MB; a decoder that is one more batch ahead (FileVideoStream keeps a
+ * queue of 128 frames, video_detect.py:86) announces it here.  The host buffer must stay valid until the next
+ * yds_pipeline_step_host call returns.  Three staging buffers: at most one prefetch per step. */
+int yds_pipeline_prefetch_host(yds_pipe *, const uint8_t *frames_host, int h, int w, int batch);
 /* bench-only: injection set (yds_darknet_load_injection_sets) to select before the prefetched detector pass */
 int yds_pipeline_set_next_injection(yds_pipe *, int set);
 /* last step, microseconds: resize (device), detector (device), host wall until NMS results, ReID, association */

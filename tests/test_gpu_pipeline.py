@@ -11,7 +11,7 @@ DS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30
 
 @pytest.mark.parametrize("name,size,batch,deep,frames_in", [("yolov3-tiny", 416, 4, False, "hbm"), ("yolov4-tiny", 416, 3, False, "hbm"),
                                                             ("yolov3-tiny", 416, 4, True, "hbm"), ("yolov3-tiny", 416, 4, False, "pinned"),
-                                                            ("yolov3-tiny", 416, 4, True, "pageable")])
+                                                            ("yolov3-tiny", 416, 4, True, "pageable"), ("yolov3-tiny", 416, 4, False, "pinned3")])
 def test_pipeline_matches_oracle_stream(name, size, batch, deep, frames_in, monkeypatch):
     # frames_in: resident in HBM (yds_pipeline_step) or handed over as host memory and uploaded by the pipeline on its
     # copy stream, double buffered (yds_pipeline_step_host; pinned = asynchronous copies, pageable = any numpy array)
@@ -54,6 +54,18 @@ def test_pipeline_matches_oracle_stream(name, size, batch, deep, frames_in, monk
             nxt = dev.offset((s + 1) * batch * frames[0].nbytes) if s + 1 < steps else None
             got += pipe.step(dev.offset(s * batch * frames[0].nbytes), 480, 640, batch, nxt,
                              select_next=(s + 1 if nxt is not None else None))
+    elif frames_in == "pinned3":
+        # a decoder three batches deep: the batch after next is announced (yds_pipeline_prefetch_host) one step before it is `next`
+        hold = [_lib.PinnedArray((batch, 480, 640, 3)) for _ in range(3)]
+        bufs = [h.array for h in hold]
+        bufs[0][:] = frames[:batch]
+        bufs[1][:] = frames[batch:2 * batch]
+        for s in range(steps):
+            if s + 2 < steps:
+                bufs[(s + 2) % 3][:] = frames[(s + 2) * batch:(s + 3) * batch]
+                pipe.prefetch_host(bufs[(s + 2) % 3])
+            nxt = bufs[(s + 1) % 3] if s + 1 < steps else None
+            got += pipe.step_host(bufs[s % 3], nxt, select_next=(s + 1 if nxt is not None else None))
     else:
         # a decoder's two-buffer ring: the batch after next overwrites the buffer of the batch that just finished
         if frames_in == "pinned":

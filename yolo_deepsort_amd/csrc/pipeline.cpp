@@ -27,45 +27,72 @@ public:
         : net(net), reid(reid), trk(trk), conf(conf), nms_thres(nms_iou), class_mask(mask, mask + n_mask) {
         for (int k = 0; k < 2; ++k) {
             for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
-            YDS_HIP(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
             nms[k].reset(new NmsWorkspace(4096, net->batch_max));
         }
+        for (int k = 0; k < NSTAGE; ++k) YDS_HIP(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
         YDS_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     }
     ~Pipeline() {
         for (int k = 0; k < 2; ++k) {
             for (hipEvent_t e : {e0[k], e1[k], e2[k], e_nms[k]}) (void)hipEventDestroy(e);
-            (void)hipEventDestroy(up_done[k]);
         }
+        for (int k = 0; k < NSTAGE; ++k) (void)hipEventDestroy(up_done[k]);
         (void)hipStreamDestroy(copy_stream);
     }
 
     // ---- frames handed over as HOST memory (img_detect.py:70-71 starts from a host frame) ------------------------------
-    // Two device staging buffers alternate; the copy runs on its own stream (SDMA engine), so the upload of batch i+1
-    // overlaps the detector / ReID / association of batch i.  The detector stream waits for the upload event of the
-    // buffer it is about to read.  Pinned source memory (yds_host_alloc) makes the copy asynchronous and full speed.
-    const uint8_t *upload(const uint8_t *host, size_t bytes) {
-        const int k = (stage_turn ^= 1);
+    // Three device staging buffers take turns; the copy runs on its own stream (SDMA engine), so uploads overlap the detector /
+    // ReID / association of earlier batches.  A batch is matched by its host pointer ONCE (the slot is forgotten when the step
+    // that consumed it returns), so a caller may reuse a host buffer for new frames.  Pinned source memory (yds_host_alloc)
+    // makes the copy asynchronous and full speed.
+    // Depth: step_host(frames, next) starts the upload of `next` when it is called - but the detector stream runs a whole pass
+    // ahead of the host chain (NMS -> ReID -> association), so it wants `next` at that very moment and would idle for the
+    // 1.7 ms of a 100 MB copy (1352 vs 1447 frames/s).  prefetch_host(frames of the step after next) starts that copy one
+    // step earlier; step_host then finds both of its batches resident.
+    int staged(const uint8_t *host) const {
+        for (int k = 0; k < NSTAGE; ++k)
+            if (host && stage_host[k] == host) return k;
+        return -1;
+    }
+    int upload(const uint8_t *host, size_t bytes, int keep_a = -1, int keep_b = -1) {
+        int k = -1;
+        for (int pass = 0; pass < 2 && k < 0; ++pass)               // next slot in turn: an empty one first, else any not in use
+            for (int t = 1; t <= NSTAGE; ++t) {
+                const int c = (stage_turn + t) % NSTAGE;
+                if (c == keep_a || c == keep_b || (pass == 0 && stage_host[c])) continue;
+                k = c;
+                break;
+            }
+        if (k < 0) fail("pipeline: no staging buffer free");
+        stage_turn = k;
         stage[k].ensure(bytes);
         YDS_HIP(hipMemcpyAsync(stage[k].p, host, bytes, hipMemcpyHostToDevice, copy_stream));
         YDS_HIP(hipEventRecord(up_done[k], copy_stream));
         stage_host[k] = host;
-        return stage[k].p;
+        up_pending[k] = true;
+        return k;
+    }
+    void prefetch_host(const uint8_t *frames_host, int h, int w, int batch) {
+        if (staged(frames_host) >= 0) return;
+        upload(frames_host, (size_t)batch * h * w * 3, cur_k, next_k);
     }
     void step_host(const uint8_t *frames_host, const uint8_t *next_host, int next_inject_set, int h, int w, int batch, int32_t *out6, int cap,
                    int32_t *counts) {
         const size_t bytes = (size_t)batch * h * w * 3;
-        const uint8_t *cur_dev = nullptr;
-        // the batch handed over as `next` by the previous call is already resident (or on its way)
-        if (prefetched_host && prefetched_host == frames_host && stage_host[stage_turn] == frames_host) cur_dev = stage[stage_turn].p;
-        else cur_dev = upload(frames_host, bytes);
-        const uint8_t *next_dev = nullptr;
-        int next_k = -1;
-        if (next_host) { next_dev = upload(next_host, bytes); next_k = stage_turn; }
-        prefetched_host = next_host;
-        step(cur_dev, next_dev, next_inject_set, h, w, batch, out6, cap, counts);
-        // both host buffers may be reused by the caller when this returns
-        if (next_k >= 0) YDS_HIP(hipEventSynchronize(up_done[next_k]));
+        // batches handed over earlier (as `next` of the previous call, or through prefetch_host) are already resident or on their way
+        cur_k = staged(frames_host);
+        if (cur_k < 0) cur_k = upload(frames_host, bytes, staged(next_host));
+        next_k = -1;
+        if (next_host) {
+            next_k = staged(next_host);
+            if (next_k < 0) next_k = upload(next_host, bytes, cur_k);
+        }
+        step(stage[cur_k].p, next_k >= 0 ? stage[next_k].p : nullptr, next_inject_set, h, w, batch, out6, cap, counts);
+        // every host buffer handed over so far may be reused by the caller when this returns; the consumed batch is forgotten
+        for (int k = 0; k < NSTAGE; ++k)
+            if (up_pending[k]) { YDS_HIP(hipEventSynchronize(up_done[k])); up_pending[k] = false; }
+        stage_host[cur_k] = nullptr;
+        cur_k = -1;
     }
 
     // One detector pass over a batch AND its NMS, all asynchronous on the detector stream.  Two NMS workspaces (and
@@ -73,8 +100,9 @@ public:
     // for and read the results of batch i: the detector stream never drains between passes.
     void launch_detector(const uint8_t *frames_dev, int h, int w, int batch, int slot = -1) {
         const int k = slot >= 0 ? slot : (in_flight_slot ^= 1);
-        for (int b = 0; b < 2; ++b)                                 // frames uploaded by step_host: wait for the copy engine
-            if (stage[b].p && frames_dev == stage[b].p) YDS_HIP(hipStreamWaitEvent(net->stream, up_done[b], 0));
+        for (int b = 0; b < NSTAGE; ++b)                            // frames uploaded by step_host: wait for the copy engine
+            if (stage[b].p && frames_dev == stage[b].p && hipEventQuery(up_done[b]) != hipSuccess)
+                YDS_HIP(hipStreamWaitEvent(net->stream, up_done[b], 0));   // (only while the copy is still running: see step())
         YDS_HIP(hipEventRecord(e0[k], net->stream));
         launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream);
         YDS_HIP(hipEventRecord(e1[k], net->stream));
@@ -182,7 +210,7 @@ public:
         // Crowded scenes (the association of a batch takes long and is all small latency-bound kernels and host syncs):
         // before associating, finish the next batch's detector + NMS and start its ReID pass, so that the matrix
         // cores stay busy underneath.  Sparse scenes keep the simpler order (the detector alone covers the association).
-        const int deep_min = getenv("YDS_PIPE_DEEP_MIN") ? atoi(getenv("YDS_PIPE_DEEP_MIN")) : 64;    // detections per frame
+        static const int deep_min = getenv("YDS_PIPE_DEEP_MIN") ? atoi(getenv("YDS_PIPE_DEEP_MIN")) : 64;    // detections per frame
         if (next_frames_dev && D_all >= deep_min * batch) {
             finish_detector(ahead, next_slot, next_frames_dev, batch);
             in_flight = nullptr;
@@ -204,10 +232,12 @@ public:
     std::unique_ptr<NmsWorkspace> nms[2];
     int in_flight_slot = 0;
     int last_h = 0, last_w = 0;
-    DevBuf<uint8_t> stage[2];                 // device copies of host frames (step_host)
-    const uint8_t *stage_host[2] = {nullptr, nullptr};
-    const uint8_t *prefetched_host = nullptr;
-    hipEvent_t up_done[2] = {};
+    static constexpr int NSTAGE = 3;
+    DevBuf<uint8_t> stage[NSTAGE];            // device copies of host frames (step_host / prefetch_host)
+    const uint8_t *stage_host[NSTAGE] = {nullptr, nullptr, nullptr};
+    bool up_pending[NSTAGE] = {false, false, false};
+    int cur_k = -1, next_k = -1;
+    hipEvent_t up_done[NSTAGE] = {};
     hipStream_t copy_stream = nullptr;
     int stage_turn = 0;
     Dets cur, ahead;                // this batch; the next batch when its ReID pass was started early
@@ -246,6 +276,11 @@ int yds_pipeline_step_host(yds_pipe *p, const uint8_t *frames_host, const uint8_
     YDS_API_BEGIN
     p->p->step_host(frames_host, next_frames_host, p->p->next_inject_set, h, w, batch, out6_host, cap, counts_host);
     p->p->next_inject_set = -1;
+    YDS_API_END
+}
+int yds_pipeline_prefetch_host(yds_pipe *p, const uint8_t *frames_host, int h, int w, int batch) {
+    YDS_API_BEGIN
+    p->p->prefetch_host(frames_host, h, w, batch);
     YDS_API_END
 }
 int yds_pipeline_set_next_injection(yds_pipe *p, int set) {

@@ -35,11 +35,23 @@ void fail(const char *fmt, ...) {
     throw Error(buf);
 }
 
-// Non-blocking stream for a handle.  (A CU partition between the convolution streams and the association stream -
-// hipExtStreamCreateWithCUMask with complementary masks - was measured in round 2 and removed: masked streams ran the
-// association 1.6x (30 persons) to 5.6x (crowd) slower, see DESIGN.md.)
-hipStream_t make_stream(bool) {
+// Non-blocking stream for a handle.  latency_role (the tracker's stream, the RCCL stream): a chain of ~200 tiny kernels per
+// batch whose completion the host waits for - created at the highest stream priority (YDS_STREAM_PRIO=0 disables), so that its
+// workgroups are dispatched ahead of the convolution streams' whenever a slot frees up: the association of a batch took
+// 5.2 ms of host time under a saturated GPU against 1.5 ms on an idle one.
+// (A CU partition between the convolution streams and the association stream - hipExtStreamCreateWithCUMask with
+// complementary masks - was measured in round 2 and removed: masked streams ran the association 1.6x (30 persons) to 5.6x
+// (crowd) slower, see DESIGN.md.)
+hipStream_t make_stream(bool latency_role) {
     hipStream_t st = nullptr;
+    static const bool use_prio = !(getenv("YDS_STREAM_PRIO") && atoi(getenv("YDS_STREAM_PRIO")) == 0);
+    if (latency_role && use_prio) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+            YDS_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest));
+            return st;
+        }
+    }
     YDS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     return st;
 }

@@ -358,7 +358,10 @@ constexpr int LSAP_NT = 256, LSAP_NW = LSAP_NT / 64;
 #ifndef YDS_LSAP_REG
 #define YDS_LSAP_REG 1                      // experiment builds: 0 = LDS-state workgroup form for every size above 64 columns
 #endif
-constexpr int LSAP_WAVE_COLS = 64;         // problems up to this many columns go to the single-wavefront kernel (below)
+#ifndef YDS_LSAP_WAVE_COLS
+#define YDS_LSAP_WAVE_COLS 64
+#endif
+constexpr int LSAP_WAVE_COLS = YDS_LSAP_WAVE_COLS;         // problems up to this many columns go to the single-wavefront kernel (below)
 constexpr size_t LSAP_STATE_BYTES = 3 * sizeof(double) + 6 * sizeof(int);      // per row / column
 constexpr size_t LSAP_LDS_MAX = 150 * 1024;
 

@@ -51,6 +51,13 @@ class Pipeline:
                                                       self.cap, _lib.ptr(counts)))
         return [None if counts[b] < 0 else out[b, :counts[b]].copy() for b in range(batch)]
 
+    def prefetch_host(self, frames):
+        """Start uploading a batch that a LATER step_host call will receive (one per step; the array must stay alive and
+        unchanged until the next step_host call returns)."""
+        assert frames.dtype == np.uint8 and frames.ndim == 4 and frames.flags["C_CONTIGUOUS"]
+        batch, h, w, _ = frames.shape
+        _lib.check(_lib.load().yds_pipeline_prefetch_host(self._h, _lib.ptr(frames), h, w, batch))
+
     def stage_us(self):
         us = np.zeros(5, np.float32)
         _lib.check(_lib.load().yds_pipeline_stage_us(self._h, _lib.ptr(us)))

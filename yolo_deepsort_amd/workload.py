@@ -66,16 +66,20 @@ class Workload:
             self.dev = _lib.DeviceBuffer.from_array(self.ring)
         return self.dev
 
-    def step(self, i, prefetch=True, host_frames=False):
+    def step(self, i, prefetch=True, host_frames=False, prefetch2=False):
         """Step i: one pass over `batch` consecutive frames.  The injection set of the detector pass that is enqueued
         inside this call must be selected before it: step i's own pass when nothing was prefetched, else step i+1's.
-        host_frames: the frames are handed over as HOST memory (pinned ring) and uploaded inside the step."""
+        host_frames: the frames are handed over as HOST memory (pinned ring) and uploaded inside the step; prefetch2: step i+2
+        will follow, its frames are announced to the pipeline now (yds_pipeline_prefetch_host)."""
         B = self.batch
         s, s_next = i % self.n_sets, (i + 1) % self.n_sets
         if self._sel != s:
             self._pl.select_injection_set(self.net, s)
             self._sel = s
         if host_frames:
+            if prefetch and prefetch2:             # the batch after next starts its upload now (a decoder two batches ahead)
+                s2 = (i + 2) % self.n_sets
+                self.pipe.prefetch_host(self.ring[s2 * B:(s2 + 1) * B])
             cur = self.ring[s * B:(s + 1) * B]
             nxt = self.ring[s_next * B:(s_next + 1) * B] if prefetch else None
             out = self.pipe.step_host(cur, nxt, select_next=(s_next if prefetch else None))
