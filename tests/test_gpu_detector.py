@@ -189,6 +189,58 @@ def test_wide_net_pre_split_layout_paths_vs_oracle(mode):
         lib.yds_set_conv_math(default)
 
 
+def _csp_cfg(ch, act):
+    """A yolov4-style CSP stage: downsample, conv 1x1 (a), route -2, conv 1x1 (b), residual block on b, conv 1x1, concat with a."""
+    def conv(f, k, s, a):
+        return f"[convolutional]\nbatch_normalize=1\nfilters={f}\nsize={k}\nstride={s}\npad=1\nactivation={a}\n\n"
+    return ("[net]\nchannels=3\nheight=64\nwidth=64\n\n" + conv(32, 3, 1, act) + conv(2 * ch, 3, 2, act)
+            + conv(ch, 1, 1, act) + "[route]\nlayers=-2\n\n" + conv(ch, 1, 1, act)
+            + conv(ch, 1, 1, act) + conv(ch, 3, 1, act) + "[shortcut]\nfrom=-3\nactivation=linear\n\n"
+            + conv(ch, 1, 1, act) + "[route]\nlayers=-1,-7\n\n" + conv(2 * ch, 1, 1, act)
+            + "[convolutional]\nsize=1\nstride=1\npad=1\nfilters=255\nactivation=linear\n\n"
+            + "[yolo]\nmask=0,1,2\nanchors=10,13, 16,30, 33,23, 30,61, 62,45, 59,119\nclasses=80\nnum=6\n")
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("ch,act", [(64, "mish"), (32, "leaky"), (24, "mish")])
+def test_csp_split_merged_launch_vs_oracle(mode, ch, act):
+    """The two 1x1 convolutions of a CSP split run as ONE launch (concatenated filters, two output views - one of them a channel
+    slice of the later concatenation): every layer against the oracle, pre-split (H16) and fp32 tensors, both conv maths, and
+    the same network with the merge disabled."""
+    import os
+    from yolo_deepsort_amd import _lib
+    lib = _lib.load()
+    default = lib.yds_get_conv_math()
+    cfg = _csp_cfg(ch, act)
+    x = np.random.RandomState(11).rand(3, 3, 64, 64).astype(F32)
+    try:
+        lib.yds_set_conv_math(mode)
+        outs = []
+        for merge in (True, False):
+            if not merge:
+                os.environ["YDS_NO_CSP_MERGE"] = "1"
+            try:
+                net, ref = _nets(cfg, (64, 64), 2, -1.0, batch_max=3)
+            finally:
+                os.environ.pop("YDS_NO_CSP_MERGE", None)
+            out = net(x)
+            want = ref.forward(x, keep_layers=True)
+            for i, d in enumerate(ref.module_defs):
+                if d["type"] == "yolo":
+                    continue
+                try:
+                    got = net.layer_output(i, 3)
+                except Exception as e:
+                    assert "fused" in str(e)
+                    continue
+                _close(got, ref.layer_outputs[i], 1e-4, 1e-4, f"merge={merge} layer {i} {d['type']}")
+            _close(out, want)
+            outs.append(np.asarray(out))
+        assert np.array_equal(outs[0], outs[1])          # same K order per output element: the merge changes no bit
+    finally:
+        lib.yds_set_conv_math(default)
+
+
 def test_both_math_modes_meet_the_tolerance():
     """f16x3 (default, split-fp16 MFMA) and the exact fp32 MFMA path against the reference's golden vector."""
     from yolo_deepsort_amd import _lib

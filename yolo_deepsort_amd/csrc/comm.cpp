@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -119,14 +120,19 @@ yds_comm *yds_comm_create(const void *id128, int world, int rank) {
     YDS_API_BEGIN
     if (yds::bound_device() < 0) yds::fail("comm: yds_init has not bound a device");
     if (world < 1 || rank < 0 || rank >= world) yds::fail("comm: rank %d outside world %d", rank, world);
-    yds_comm *c = new yds_comm;
+    std::unique_ptr<yds_comm> c(new yds_comm);
     c->world = world;
     c->rank = rank;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     c->stream = yds::make_stream(true);
-    YDS_NCCL(yds::rccl().CommInitRank(&c->comm, world, id, rank));      // collective: every rank of the job calls it
-    return c;
+    try {
+        YDS_NCCL(yds::rccl().CommInitRank(&c->comm, world, id, rank));  // collective: every rank of the job calls it
+    } catch (...) {
+        (void)hipStreamDestroy(c->stream);
+        throw;
+    }
+    return c.release();
     YDS_API_END_PTR
 }
 

@@ -18,6 +18,7 @@
 #include "conv_common.h"
 
 #include <map>
+#include <mutex>
 
 #include <math.h>
 #include <string.h>
@@ -555,7 +556,10 @@ int conv_splitk_factor(const ConvKernelArgs &k, int BM, int BN) {
 
 static float *splitk_workspace(size_t floats, hipStream_t s) {
     // one grow-only slab set per stream (the detector and the ReID network run concurrently on their own streams)
+    // (handles may be driven from different host threads: the map is guarded; a slab is only ever used on its own stream)
+    static std::mutex mu;
     static std::map<hipStream_t, DevBuf<float>> bufs;
+    std::lock_guard<std::mutex> lock(mu);
     DevBuf<float> &b = bufs[s];
     if (b.n < floats) {
         YDS_HIP(hipStreamSynchronize(s));

@@ -269,7 +269,7 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
     }
     // ---- pass 5: CSP splits.  conv a (1x1) / route to a's input / conv b (1x1): both read the same tensor; one launch
     //      with the filters of both (a's first) writes a's channels to a's view and b's to b's view.
-    static const bool no_merge = getenv("YDS_NO_CSP_MERGE") != nullptr;
+    const bool no_merge = getenv("YDS_NO_CSP_MERGE") != nullptr;     // (read at plan time: tests build both forms in one process)
     for (int i = 1; i + 2 < L && !no_merge; ++i) {
         Layer &a = layers[i];
         const Layer &r = layers[i + 1];
