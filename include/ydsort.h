@@ -183,6 +183,9 @@ int yds_tracker_nms(const float *tlwh_host, const int32_t *order_host, int D, do
 int yds_tracker_num_tracks(const yds_trk *);
 int yds_tracker_get_state(yds_trk *, int32_t *ids, int32_t *state, int32_t *tsu, int32_t *hits,
                           float *mean8, float *cov64, int cap, int *T);
+/* rows every track's appearance gallery can hold right now: nn_budget, or - with nn_budget=None - the capacity the unbounded
+ * galleries have grown to (it follows the longest gallery a LIVE track holds, nn_matching.py:152-156 keeps active targets only) */
+int yds_tracker_gallery_rows(const yds_trk *);
 /* Track.payload of every live track, in track-list order (deep_sort/sort/track.py:77,141: the class id the demo passes) */
 int yds_tracker_get_payload(yds_trk *, float *payload, int cap);
 int yds_tracker_last_unmatched(yds_trk *, int32_t *um_tracks, int cap_t, int *n_t,

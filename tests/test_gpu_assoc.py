@@ -560,3 +560,27 @@ def _keep_with_order(ds, tlwh, order):
     n = C.c_int(0)
     L.check(L.load().yds_tracker_nms(L.ptr(tlwh), L.ptr(order), d, float(ds.nms_max_overlap), L.ptr(pick), C.byref(n)))
     return pick[:n.value].copy()
+
+
+def test_unbounded_galleries_follow_live_tracks_not_frames_seen():
+    """nn_budget=None: the per-track row capacity grows with the longest gallery a LIVE track holds - a stream whose
+    tracks die young must not grow it with every frame (it used to double by frames seen: ~8.6 GB after 1k frames in pipeline
+    mode), while a long-lived track still gets every row (reference nn_matching.py:152-156)."""
+    from yolo_deepsort_amd.deep_sort import _TrackerHandle
+    L = _lib()
+    lib = L.load()
+    trk = _TrackerHandle(0.3, 0.7, 3, 3, None)                    # max_age 3: a track that stops being detected dies within 4 frames
+    rng = np.random.RandomState(5)
+    feats = rng.randn(400, 512).astype(F32)
+    cap0 = lib.yds_tracker_gallery_rows(trk._h)
+    for t in range(400):
+        gen = t // 20                                             # every 20 frames a new set of persons replaces the old one
+        ids = np.arange(6) + 6 * gen
+        tlwh = np.stack([100.0 + 150 * (ids % 6), 100.0 + 5 * (t % 20) + 0 * ids, 60.0 + 0 * ids, 120.0 + 0 * ids], 1).astype(F32)
+        trk.step(tlwh, feats[ids % 400], np.zeros(6, F32))
+    assert lib.yds_tracker_num_tracks(trk._h) <= 12
+    assert cap0 <= lib.yds_tracker_gallery_rows(trk._h) <= 64      # galleries never exceeded ~20 rows; 400 frames seen
+    keep = _TrackerHandle(0.3, 0.7, 30, 3, None)
+    for t in range(150):                                          # one long-lived person: 150 rows must fit
+        keep.step(np.array([[200.0 + t, 200.0, 60.0, 120.0]], F32), feats[:1], np.zeros(1, F32))
+    assert lib.yds_tracker_gallery_rows(keep._h) >= 150 and keep.state()["hits"][0] == 150

@@ -1561,6 +1561,7 @@ int yds_tracker_get_state(yds_trk *t, int32_t *ids, int32_t *state, int32_t *tsu
     }
     YDS_API_END
 }
+int yds_tracker_gallery_rows(const yds_trk *t) { return impl(t)->budget; }
 int yds_tracker_get_payload(yds_trk *t, float *payload, int cap) {
     YDS_API_BEGIN
     yds::Tracker *k = impl(t);
