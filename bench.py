@@ -305,7 +305,7 @@ def main():
                                          "lookahead1 = the next frame is handed over one step early (its detector pass overlaps this frame's association)",
             "stage_us_frame_by_frame": None if fbf_stage is None else {k: round(v, 1) for k, v in fbf_stage.items()},
             "exchange": None if world == 1 else "all-gather of {count, rows[256][6]} per frame per rank after every step (%s)" % (
-                "RCCL via yds_comm_*" if ranks.comm is not None else "gloo"),
+                "RCCL via yds_comm_*" if ranks.comm is not None else ("gloo" + (f"; RCCL unavailable: {ranks.fallback_reason}" if ranks.fallback_reason else ""))),
             "stage_us_last_step": {k: round(v, 1) for k, v in stage.items()},
             "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
             "roofline": roofline, "power_experiment": power, "conv_variants": variants, "cpu_baseline": cpu,

@@ -100,6 +100,18 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
     assert total == line["config"]["tracker_rows_out"] and total > 0                            # rank 0 holds BOTH streams' rows
 
 
+def test_rccl_refusal_falls_back_to_the_host_group(tmp_path):
+    """Two ranks on ONE device with the RCCL backend asked for: rank 0 creates the id, both ranks call ncclCommInitRank, RCCL
+    refuses (duplicate GPU) - every rank must then agree on the gloo transport and the run must complete (a scaling run must
+    not die because the collective library could not come up)."""
+    env = dict(os.environ, YDS_DEVICE="0")
+    env.pop("YDS_DIST_BACKEND", None)
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29583"]
+    line = _bench(tmp_path, ["--gpus", "2", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--batch", "4"], env, launcher)
+    assert line["n_gpus"] == 2 and line["exchange"].startswith("all-gather") and "RCCL unavailable" in line["exchange"]
+    assert line["config"]["tracker_rows_out"] > 0
+
+
 def test_rccl_comm_world_of_one():
     """yds_comm_* on RCCL itself (ncclCommInitRank / ncclAllGather / ncclAllReduce) - a world of one rank is all a 1-GPU box
     can form; the collectives must round-trip the exchange block and the reductions."""

@@ -51,6 +51,7 @@ class Ranks:
         self.backend = backend or "nccl"
         self.dist = None                 # host-side group (gloo)
         self.comm = None                 # yds_comm handle (RCCL) once connect() ran
+        self.fallback_reason = None      # why connect() stayed on the host group although "nccl" was asked for
         if self.world > 1:
             # libydsort (and with it the HIP runtime it is linked against) is mapped BEFORE torch brings its own ROCm libraries
             from . import _lib
@@ -67,12 +68,37 @@ class Ranks:
         from . import _lib
         lib = _lib.load()
         _lib.init()
+        import torch
         ident = (C.c_char * 128)()
+        err = None
         if self.rank == 0:
-            _lib.check(lib.yds_comm_unique_id(ident))
-        box = [bytes(ident.raw)]
+            try:
+                _lib.check(lib.yds_comm_unique_id(ident))
+            except _lib.YdsError as e:
+                err = str(e)
+        box = [bytes(ident.raw), err]
         self.dist.broadcast_object_list(box, src=0)
-        self.comm = _lib.check_ptr(lib.yds_comm_create(C.create_string_buffer(box[0], 128), self.world, self.rank))
+        comm = None
+        if box[1] is None:
+            try:
+                comm = _lib.check_ptr(lib.yds_comm_create(C.create_string_buffer(box[0], 128), self.world, self.rank))
+            except _lib.YdsError as e:
+                err = str(e)
+        else:
+            err = box[1]
+        # every rank must end up on the same transport: if RCCL could not be brought up anywhere, all of them stay on the host group
+        ok = torch.tensor([1 if comm else 0], dtype=torch.int32)
+        self.dist.all_reduce(ok, op=self.dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            self.comm = comm
+        else:
+            if comm:
+                lib.yds_comm_destroy(comm)
+            self.fallback_reason = err or "RCCL initialisation failed on another rank"
+            self.backend = "gloo"
+            if self.rank == 0:
+                import sys
+                print(f"[yolo_deepsort_amd.dist] RCCL communicator not available ({self.fallback_reason}); exchange step falls back to gloo", file=sys.stderr)
         return self
 
     def stream_seed(self, base=0):

@@ -15,7 +15,7 @@ CONFIGS = {
     "cfg2": dict(net="yolov3", persons=30, visible=None, workload="yolov3.cfg 608x608 + DeepSORT, synthetic 1080p stream, 30 persons/frame"),
     "cfg3": dict(net="yolov4", persons=30, visible=None, workload="yolov4.cfg 608x608 + DeepSORT, synthetic 1080p stream, 30 persons/frame"),
     # BASELINE configs[3]: cfg3 on every rank, one independent stream per GPU (stream seed = rank; bench.py --gpus N)
-    "cfg4": dict(net="yolov4", persons=30, visible=None, workload="yolov4.cfg 608x608 + DeepSORT, independent synthetic 1080p streams (seed = rank), one per GPU, result rows all-gathered over RCCL"),
+    "cfg4": dict(net="yolov4", persons=30, visible=None, workload="yolov4.cfg 608x608 + DeepSORT, independent synthetic 1080p streams (seed = rank), one per GPU, result rows all-gathered after every step (transport: `exchange`)"),
     "cfg5": dict(net="yolov4", persons=200, visible=150, workload="yolov4.cfg 608x608 + DeepSORT, crowd stream 200 tracks / 150 detections per frame"),
 }
 DS_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)   # video_deepsort.py:18-25
