@@ -17,6 +17,9 @@
 // address of the DMA and again by the fragment reads; 16 consecutive rows hit 16 distinct bank slots at any base.
 #include "conv_common.h"
 
+#ifndef YDS_WIN_AMAJOR
+#define YDS_WIN_AMAJOR 0
+#endif
 #ifndef YDS_WIN_ABL
 #define YDS_WIN_ABL 0      // experiment builds: 1 no DMA in the K loop, 2 + no fragment reads, 3 no MFMA, 4 no barrier / vmcnt wait, 5 no K loop
 #endif
@@ -140,7 +143,18 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
             fr[s][f] = *reinterpret_cast<const h8 *>(bst + b_frag + (which - TM) * 32 * ROW + (lo ? bpos_lo[s] : bpos_hi[s]));
         }
     };
-    auto mfma = [&](int s, int m) {
+    auto mfma = [&](int s, int m0) {
+#if YDS_WIN_AMAJOR
+        // experiment: operand-major order - consecutive MFMAs keep their A operand (Ah_i x {Bh_j, Bl_j}..., then Al_i x {Bh_j}...)
+        int m = m0;
+        {
+            const int per_i = 3 * TN, i = m0 / per_i, r = m0 % per_i;
+            if (r < 2 * TN) m = (i * TN + r / 2) * 3 + (r & 1);          // Ah_i x Bh_j (term 0), Ah_i x Bl_j (term 1)
+            else m = (i * TN + (r - 2 * TN)) * 3 + 2;                      // Al_i x Bh_j (term 2)
+        }
+#else
+        const int m = m0;
+#endif
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
         if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
