@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")
+    ap.add_argument("--cross8", action="store_true", help="opt-in tier: the window 3x3 kernel computes the cross terms of the f16x3 product in fp8 e4m3 "
+                                                          "(models.set_conv_cross8; not the metric's arithmetic: heads move by ~1e-5 of their maximum)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` on its own launches the N ranks itself (one process per GPU, rendezvous on 127.0.0.1);
@@ -137,6 +139,8 @@ def main():
     ranks.connect()                # RCCL communicator on the bound device (N > 1)
 
     B, K, W = args.batch, args.steps, args.warmup
+    if args.cross8:
+        _lib.check(lib.yds_set_conv_cross8(1))
     wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
     cfg = wl.cfg
     wl.to_device()
@@ -161,6 +165,8 @@ def main():
     flops_frame = wl.flops_per_frame()
     stage = wl.pipe.stage_us()
     math_name = {0: "f32", 1: "f16x3", 2: "f16"}[lib.yds_get_conv_math()] if not args.half else "f16"
+    if args.cross8 and math_name == "f16x3":
+        math_name = "f16x3, window 3x3 kernel: fp16 hi x hi + fp8 e4m3 cross terms"
 
     # ---- the same steps with the frames coming from pinned host memory (PCIe inside the timed region)
     dt_up = None
@@ -191,6 +197,11 @@ def main():
             # (a third of the conv FLOPs, not counted here) share the CUs from a second stream during part of every detector pass
             ov_same = next((v for v in variants if v["name"] == iso_dom["kernel"] and v["launches"]), None)
             dom_ov, dom = dom, iso_dom
+            peak_all = peak
+            if args.cross8 and f16x3 and dom["kernel"].startswith("conv3x3_f16x3_win<256,128"):
+                # the dominant kernel's own bound in this mode: 128 instead of 192 pipe cycles per 32 channels and accumulator tile
+                peak = PEAK_F16_MFMA_TFLOPS / 2
+                dom["frac"] = dom["achieved"] / peak
             roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(dom["achieved"], 2), peak=round(peak, 1),
                             unit="TFLOP/s", frac=round(dom["frac"], 4), traffic=None,
                             timing="HIP event pairs around every conv launch on the detector stream, no host synchronisation inside a pass: "
@@ -198,7 +209,9 @@ def main():
                                    "(prefetched, ReID / association streams live)",
                             frac_overlapped=None if ov_same is None else round(ov_same["flops"] / ov_same["us"] / 1e6 / peak, 4),
                             dominant_kernel_overlapped=dom_ov["kernel"],
-                            peak_note=("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
+                            peak_note=("cross8: two fp16 MFMAs + one fp8 K=64 MFMA per 32 channels = 2500 / 2 TFLOP/s fp32-equivalent (the other kernels: 2500 / 3)"
+                                       if args.cross8 and peak != peak_all else
+                                       "dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
                                        else ("dense fp16 MFMA" if args.half else "fp32-input MFMA, 64 FLOP/clk/SIMD")),
                             frac_of_fp32_mfma_peak=round(dom["achieved"] / PEAK_F32_MFMA_TFLOPS, 4),
                             # pure-MFMA loop on random fp16 data, sustained (power limited): profiles/r01_ablation_dma.txt #6
@@ -218,7 +231,7 @@ def main():
                                                   us_per_frame_overlapped=round(allc["measured_us"] / ((K + W) * B), 1)),
                             # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
                             # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
-                            pipeline_conv_frac=round(flops_frame * frames_total_for_frac / dt / 1e12 / peak, 4),
+                            pipeline_conv_frac=round(flops_frame * frames_total_for_frac / dt / 1e12 / peak_all, 4),
                             # the peak assumes 2.4 GHz; the chip is power limited under this load: clock sampled INSIDE the window
                             # kernels (s_memtime / s_memrealtime, one workgroup in 32) over the timed region
                             sustained_clock_ghz=round(clock_ghz, 3), nominal_clock_ghz=2.4,

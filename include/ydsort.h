@@ -255,6 +255,12 @@ int yds_conv_num_variants(void);
  * relative).  Default 1; env YDS_CONV_MATH=f32|f16x3 overrides the default. */
 int yds_set_conv_math(int mode);
 int yds_get_conv_math(void);
+/* Opt-in precision tier between the default and half=True (no reference counterpart; models.py runs fp32 or .half()): the
+ * window-resident 3x3 convolution kernel keeps the hi x hi term of the split-fp16 product on the fp16 matrix pipe and computes
+ * the two cross terms in fp8 e4m3 (one K=64 MFMA per 32 channels instead of four fp16 ones).  Detector heads move by 2-5e-5 of
+ * their maximum (default mode: 2e-6, half: 1e-3).  Process wide like yds_set_conv_math; env YDS_CONV_CROSS8=1 sets the initial value. */
+int yds_set_conv_cross8(int on);
+int yds_get_conv_cross8(void);
 const char *yds_conv_variant_name(int variant);
 /* Kernel tuning aid: time `iters` launches of one conv layer on random data (HIP events); returns the
  * average launch duration in us and the tile variant that was picked. */
@@ -266,7 +272,8 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
  * is power limited well below that, which bench.py reports next to the nominal roofline fraction. */
 int yds_conv_clock(double *ghz, double *sampled_ms, int reset);
 /* tuning aid (YDS_TIMING / YDS_TIMING2 experiment builds only): accumulated s_memtime phase counters of the LDS-DMA conv kernel
- * (reset = 0 / 1) or of the two-workgroup window kernel (reset = 2 / 3: wait, barrier, body, prologue, epilogue, total, steps, waves) */
+ * (reset = 0 / 1), of the two-workgroup window kernel (reset = 2 / 3: wait, barrier, body, prologue, epilogue, total, steps, waves) or of
+ * the 512-thread window kernel (YDS_TIMING_WIN; reset = 4 / 5: prologue, K loop, epilogue cycles, sampled workgroups) */
 int yds_debug_prof(uint64_t *out8, int reset);
 /* parity-test entry: one convolution through a chosen kernel variant (formats as the planner would pick them for the
  * current conv math).  x NHWC [n,h,w,cin], w [cout][kh][kw][cin] (BN already folded), res NHWC or NULL

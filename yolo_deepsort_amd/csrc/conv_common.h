@@ -30,6 +30,8 @@ struct ConvKernelArgs {
     int act, res_mode;
     int fmt_x, fmt_y, fmt_r;              // TensorFmt of input, output and residual views
     int terms;                            // 3: f16x3, 1: hi halves only (half mode; LDS-DMA and window kernels)
+    const void *w8 = nullptr;             // window kernel, cross8 mode: filters as [32 wh fp16 | 32 wl8 | 32 wh8] per K chunk (else null)
+    int w8_shift = 0;                     //   wl8 / wh8 = e4m3(w * 2^w8_shift)
     int ksplit = 1;                       // LDS-DMA kernel: K ranges (grid.y); > 1 writes raw partial sums into slab blockIdx.y of y
     // two convolutions of the same input in one launch (CSP split, darknet.cpp): filters [n_split, Cout) write to y2
     float *y2 = nullptr;
@@ -278,6 +280,7 @@ void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
 void conv_win_clock(unsigned long long *cycles_ticks, bool reset);
 void conv_win2_clock(unsigned long long *cycles_ticks, bool reset);
 void conv_win2_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING2 builds: wait, barrier, body, prologue, epilogue, total cycles, steps, waves
+void conv_win_debug_prof(unsigned long long *out, bool reset);    // YDS_TIMING_WIN builds: prologue, K loop, epilogue cycles of the sampled workgroups, their count
 void conv_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING builds: wait / barrier / body / total cycles, steps, waves
 
 }  // namespace yds
