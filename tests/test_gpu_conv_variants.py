@@ -153,6 +153,7 @@ def test_window_kernel_cross8_mode_vs_float64():
     names = [lib.yds_conv_variant_name(v).decode() for v in range(lib.yds_conv_num_variants())]
     win = names.index("conv3x3_f16x3_win<256,128,4x2>")
     assert lib.yds_get_conv_math() == 1
+    prev = lib.yds_get_conv_cross8()
     rng = np.random.RandomState(23)
     cases = [(2, 19, 19, 64, 128, "leaky", 0), (1, 38, 38, 128, 256, "leaky", 1), (2, 76, 76, 64, 128, "mish", 1), (5, 13, 13, 32, 96, "mish", 0),
              (7, 8, 4, 256, 256, "relu", 2), (1, 12, 304, 32, 64, "leaky", 1), (1, 19, 19, 512, 1024, "linear", 0)]
@@ -180,4 +181,4 @@ def test_window_kernel_cross8_mode_vs_float64():
             assert e_x8 > 2 * e_base, "cross8 mode was not active"
             assert np.array_equal(base, again)
     finally:
-        lib.yds_set_conv_cross8(0)
+        lib.yds_set_conv_cross8(prev)
