@@ -10,7 +10,7 @@ typedef int i8v __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void probe(float *out, int steps, unsigned seed) {
+__global__ __launch_bounds__(256, 2) void probe(float *out, int steps, unsigned seed, unsigned lo_mask) {
     const int tid = threadIdx.x;
     unsigned h = (tid + 977u * blockIdx.x + seed) * 2654435761u;
     auto rnd = [&]() { h = h * 1664525u + 1013904223u; return h; };
@@ -21,10 +21,12 @@ __global__ __launch_bounds__(256, 2) void probe(float *out, int steps, unsigned 
         for (int k = 0; k < 4; ++k) t.u[k] = ((rnd() >> 3) & 0x03ff03ffu) | 0x38003800u | (rnd() & 0x80008000u);
         ah[i] = t.v;
         for (int k = 0; k < 4; ++k) t.u[k] = ((rnd() >> 3) & 0x03ff03ffu) | 0x38003800u | (rnd() & 0x80008000u);
+        for (int k = 0; k < 4; ++k) t.u[k] &= lo_mask;          // MODE 0 experiment: lo halves with their low mantissa bits cleared
         al[i] = t.v;
         for (int k = 0; k < 4; ++k) t.u[k] = ((rnd() >> 3) & 0x03ff03ffu) | 0x38003800u | (rnd() & 0x80008000u);
         bh[i] = t.v;
         for (int k = 0; k < 4; ++k) t.u[k] = ((rnd() >> 3) & 0x03ff03ffu) | 0x38003800u | (rnd() & 0x80008000u);
+        for (int k = 0; k < 4; ++k) t.u[k] &= lo_mask;
         bl[i] = t.v;
         for (int k = 0; k < 8; ++k) { a8[i][k] = (int)((rnd() & 0x87878787u) | 0x30303030u); b8[i][k] = (int)((rnd() & 0x87878787u) | 0x30303030u); }   // e4m3 in [0.5, 2), random signs
     }
@@ -59,13 +61,13 @@ __global__ __launch_bounds__(256, 2) void probe(float *out, int steps, unsigned 
     if (t == 12345.678f) out[0] = t;
 }
 
-template <int MODE> double run(int blocks, int steps) {
+template <int MODE> double run(int blocks, int steps, unsigned lo_mask = 0xffffffffu) {
     float *d; hipMalloc(&d, 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d, steps / 8, 1u);
+    hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d, steps / 8, 1u, lo_mask);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d, steps, 7u + r);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, d, steps, 7u + r, lo_mask);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipFree(d);
@@ -79,6 +81,12 @@ int main() {
         double t0 = run<0>(blocks, steps), t1 = run<1>(blocks, steps);
         printf("3 x fp16 MFMA per k16        : %8.2f ms  %7.1f TFLOP/s fp32-equivalent\n", t0, 2 * macs / t0 / 1e9);
         printf("fp16 hi x hi + fp8 cross terms: %8.2f ms  %7.1f TFLOP/s fp32-equivalent   (x%.2f)\n", t1, 2 * macs / t1 / 1e9, t0 / t1);
+    }
+    // does the energy of an fp16 MFMA depend on how many mantissa bits of an operand are populated?  (lo halves truncated to n bits)
+    for (int bits = 10; bits >= 0; bits -= 2) {
+        const unsigned m16 = 0xffffu & ~((1u << (10 - bits)) - 1u), mask = m16 | (m16 << 16);
+        double t = run<0>(blocks, steps, mask);
+        printf("3 x fp16 MFMA, lo halves with %2d mantissa bits: %8.2f ms  %7.1f TFLOP/s\n", bits, t, 2 * macs / t / 1e9);
     }
     return 0;
 }
