@@ -151,7 +151,7 @@ def test_window_kernel_cross8_mode_vs_float64():
     lib = L.load()
     lib.yds_conv_variant_name.restype = C.c_char_p
     names = [lib.yds_conv_variant_name(v).decode() for v in range(lib.yds_conv_num_variants())]
-    win = names.index("conv3x3_f16x3_win<256,128,4x2>")
+    wins = [names.index(n) for n in ("conv3x3_f16x3_win<256,128,4x2>", "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>")]
     assert lib.yds_get_conv_math() == 1
     prev = lib.yds_get_conv_cross8()
     rng = np.random.RandomState(23)
@@ -168,17 +168,18 @@ def test_window_kernel_cross8_mode_vs_float64():
             res = rng.standard_normal((n, h, wd, cout)).astype(F32) if res_mode else None
             want = _conv_ref(x, w, bias, 3, 1, ACT[act], res, res_mode)
             scale = float(np.abs(want).max())
-            L.check(lib.yds_set_conv_cross8(0))
-            base = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
-            L.check(lib.yds_set_conv_cross8(1))
-            assert lib.yds_get_conv_cross8() == 1
-            got = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
-            L.check(lib.yds_set_conv_cross8(0))
-            again = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
-            e_base, e_x8 = float(np.abs(base - want).max()) / scale, float(np.abs(got - want).max()) / scale
-            assert np.isfinite(got).all()
-            assert e_base < 5e-6 and e_x8 < (1e-3 if outliers else 5e-5), ((n, h, wd, cin, cout, act, res_mode), e_base, e_x8)
-            assert e_x8 > 2 * e_base, "cross8 mode was not active"
-            assert np.array_equal(base, again)
+            for win in wins:                                   # every tile shape of the window kernel has the mode
+                L.check(lib.yds_set_conv_cross8(0))
+                base = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
+                L.check(lib.yds_set_conv_cross8(1))
+                assert lib.yds_get_conv_cross8() == 1
+                got = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
+                L.check(lib.yds_set_conv_cross8(0))
+                again = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
+                e_base, e_x8 = float(np.abs(base - want).max()) / scale, float(np.abs(got - want).max()) / scale
+                assert np.isfinite(got).all()
+                assert e_base < 5e-6 and e_x8 < (1e-3 if outliers else 5e-5), (names[win], (n, h, wd, cin, cout, act, res_mode), e_base, e_x8)
+                assert e_x8 > 2 * e_base, "cross8 mode was not active"
+                assert np.array_equal(base, again)
     finally:
         lib.yds_set_conv_cross8(prev)

@@ -41,8 +41,13 @@ def main():
         pass
     # timing
     os.environ["YDS_CONV_FORCE"] = str(win)
+    if os.environ.get("CROSS8_WIDE64"):                          # the 64-filter tile shapes (ReID 64->64 at 480 crops)
+        os.environ["YDS_CONV_FORCE"] = str(names.index("conv3x3_f16x3_win<256,64,%s>" % os.environ["CROSS8_WIDE64"]))
+        shapes64 = [(480, 64, 32, 64, 64, 3, 0), (16, 152, 76, 64, 64, 2, 1)]
     shapes = [(16, 76, 76, 128, 256, 1, 1), (16, 38, 38, 256, 512, 1, 1), (16, 19, 19, 512, 1024, 1, 1), (16, 152, 152, 64, 128, 1, 1),
               (16, 76, 76, 128, 128, 2, 0), (16, 38, 38, 256, 256, 2, 0), (16, 19, 19, 512, 512, 2, 0)]
+    if os.environ.get("CROSS8_WIDE64"):
+        shapes = shapes64
     for n, h, wd, cin, cout, act, res in shapes:
         row = []
         clk = []

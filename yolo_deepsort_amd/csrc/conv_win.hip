@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         constexpr int PREV_DMA = !YDS_WIN_DEEP || (TAP == 7 && !LAST) ? 0 : TAP == 0 ? B_INST : ((!LAST && TAP - 1 < APW) ? 1 : 0) + (!(LAST && TAP - 1 + AHEAD > 8) ? B_INST : 0);
         constexpr int NH = 2 * (TM + TN), NX = TM * TN, NHH = 2 * TM * TN;
         constexpr int OPS = (1 + B_INST + NH + NX - 1) / NX;
-        static_assert(NH <= NHH, "not enough MFMA slots in substep 0");
+        constexpr int XR = (NH + NHH - 1) / NHH;                // fp8 fragment halves per substep-0 slot (1; 2 for the 64-filter tiles)
         const int g1 = TAP + 1 >= 9 ? g + 1 : g, g2 = TAP + AHEAD >= 9 ? g + 1 : g;
         const char *bst = bring + (TAP % NSB) * B_STAGE, *bst1 = bring + ((TAP + 1) % NSB) * B_STAGE;
 #pragma unroll
@@ -333,7 +333,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
             const int s = m / (TM * TN), ij = m % (TM * TN), i = ij / TN, j = ij % TN;
             acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[2 * i + s], fh[2 * (TM + j) + s], acc1[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (m < NH && YDS_WIN_ABL != 2) x_read(bst, frag_order(m));
+#pragma unroll
+            for (int r = m * XR; r < (m + 1) * XR; ++r)
+                if (r < NH && YDS_WIN_ABL != 2) x_read(bst, frag_order(r));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (YDS_WIN_ABL != 4) {
@@ -484,10 +486,20 @@ bool conv_win_applicable(const ConvKernelArgs &k) {
 
 void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
     if (!conv_win_applicable(k)) fail("conv: the window-resident kernel needs a 3x3 stride-1 layer with a pre-split input and W <= 95 (W <= 318 for 32 input channels)");
-    if (k.terms != 1 && k.w8 && shape == 0) {                    // cross8 mode: fp16 hi x hi + fp8 cross terms (256x128 tiles only)
+    if (k.terms != 1 && k.w8) {                                  // cross8 mode: fp16 hi x hi + fp8 cross terms
+        if (shape == 0) {
 #define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R, 2>(k, s)
-        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
+        } else if (shape == 1) {
+#define YDS_CALL(A, R) launch_inst_win<64, 8, 1, A, R, 2>(k, s)
+            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        } else {
+#define YDS_CALL(A, R) launch_inst_win<64, 4, 2, A, R, 2>(k, s)
+            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        }
     } else if (k.terms == 1) {                                   // half mode: one instantiation family (256x128, or 256x64 for narrow layers)
         if (shape == 0) {
 #define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R, 1>(k, s)

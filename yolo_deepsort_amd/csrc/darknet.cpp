@@ -563,7 +563,7 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
                 rec.bytes = conv_bytes(a) + extra_bytes;
                 // bound of the arithmetic the launch really used: f16x3 = three fp16 MFMAs per product block; the window kernel's
                 // cross8 mode = 128 instead of 192 pipe cycles per 32 channels (two fp16 + one fp8 K=64 instruction)
-                const bool cross8 = variant == kF32Variants + 8 && a.terms != 1 && a.w16x && conv_cross8() && extra_flops == 0.0;
+                const bool cross8 = variant >= kF32Variants + 8 && variant <= kF32Variants + 10 && a.terms != 1 && a.w16x && conv_cross8() && extra_flops == 0.0;
                 const double peak = conv_math() == MATH_F32 ? 157.3e12 : (a.terms == 1 ? 2500e12 : (cross8 ? 2500e12 / 2 : 2500e12 / 3));
                 rec.attain_us = std::max(rec.flops / peak, rec.bytes / 6.29e12) * 1e6;
                 conv_pending.push_back(rec);
