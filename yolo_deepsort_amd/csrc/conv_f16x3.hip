@@ -306,7 +306,13 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     }
     // logical chunk fetched by this lane: position dpos of row r holds chunk dpos ^ ((r >> 1) & 7); r % 8 == drow for
     // every instruction (row bases are multiples of 8) and bit 3 of r is bit 0 of (q*NW + wave)
-    auto src_chunk = [&](int q) { return (dpos ^ ((((q * NW + wave) * 8 + drow) >> 1) & 7)) * 16; };
+    // TERMS = 4 (half mode, 64 channels per K step): an LDS row is gathered from the hi halves of two consecutive channel groups -
+    // logical chunks 0-3 = chunks 0-3 of group 2q's record, 4-7 = chunks 0-3 of group 2q+1's (see conv_win.hip)
+    constexpr int KC = TERMS == 4 ? 64 : 32;                    // channels per K step
+    auto src_chunk = [&](int q) {
+        const int c = dpos ^ ((((q * NW + wave) * 8 + drow) >> 1) & 7);
+        return (TERMS == 4 ? ((c >> 2) << 3) + (c & 3) : c) * 16;
+    };
     const char *w_src[B_INST];
 #pragma unroll
     for (int q = 0; q < B_INST; ++q) {
@@ -316,7 +322,7 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     // split-K (gridDim.y > 1): this workgroup accumulates K tiles [t_begin, t_begin + nk) only and writes raw fp32 partial
     // sums into slab blockIdx.y of the workspace p.y (the launcher passes zero bias / linear / no residual / fp32 output);
     // splitk_reduce_kernel adds the slabs in a fixed order and applies the real epilogue.
-    const int nk_all = p.K / 32;                                // Cin % 32 == 0 on this path
+    const int nk_all = p.K / KC;                                // Cin % KC == 0 on this path
     int t_begin = 0, nk = nk_all;
     if (gridDim.y > 1) {
         const int per = (nk_all + gridDim.y - 1) / gridDim.y;
@@ -324,10 +330,10 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         nk = max(0, min(nk_all, t_begin + per) - t_begin);
         p.y += (size_t)blockIdx.y * (size_t)p.M * p.ldy;
     }
-    const int kcs = p.Cin / 32;
-    int kh = (t_begin / kcs) / p.ksize, kw = (t_begin / kcs) % p.ksize, kc = (t_begin % kcs) * 32;   // (tap, channel group) of the next tile to issue
+    const int kcs = p.Cin / KC;
+    int kh = (t_begin / kcs) / p.ksize, kw = (t_begin / kcs) % p.ksize, kc = (t_begin % kcs) * KC;   // (tap, channel group) of the next tile to issue
 #pragma unroll
-    for (int q = 0; q < B_INST; ++q) w_src[q] += (size_t)t_begin * 128;
+    for (int q = 0; q < B_INST; ++q) w_src[q] += (size_t)t_begin * (KC * 4);
     auto set_tap = [&]() {
 #pragma unroll
         for (int q = 0; q < A_INST; ++q) {
@@ -345,11 +351,11 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         } else {
             const int b = q - A_INST;
             __builtin_amdgcn_global_load_lds((glb_void_t *)w_src[b], (lds_void_t *)(sb + (b * NW + wave) * 8 * ROW), 16, 0, 0);
-            w_src[b] += 128;
+            w_src[b] += KC * 4;
         }
     };
     auto advance_tile = [&]() {
-        kc += 32;
+        kc += KC;
         if (kc >= p.Cin) { kc = 0; if (++kw == p.ksize) { kw = 0; ++kh; } set_tap(); }
     };
 
@@ -395,6 +401,11 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
         if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
+        if (TERMS == 4) {                                        // both slots hold hi values (of two channel groups)
+            if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
+            else if (term == 1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, acc1[i][j], 0, 0, 0);
+            return;
+        }
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
         else if (term == 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[i][j], 0, 0, 0);
         else acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[i][j], 0, 0, 0);
@@ -467,7 +478,7 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
+                acc1[i][j][e] = TERMS != 3 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     // whole-tile staging: the launcher sizes the LDS as max(ring, BM x (BN+4) floats)
     conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT, true>(p, acc1, reinterpret_cast<float *>(ring), m0, n0, tid);
 }
@@ -497,6 +508,12 @@ template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS> s
 template <int BM, int BN, int WM, int WN, int NS> static void launch_cfg_dma(const ConvKernelArgs &k, hipStream_t s) {
     if (k.fmt_x != FMT_H16 || k.Cin % 32) fail("conv: the LDS-DMA kernel needs a pre-split (H16) input");
     if ((size_t)k.Cin * 4 + 128 > (size_t)ZERO_PAGE_BYTES) fail("conv: %d input channels exceed the zero page of the LDS-DMA kernel", k.Cin);
+    if (k.terms == 1 && k.Cin % 64 == 0 && !getenv("YDS_HALF_NARROW")) {      // half mode, 64 channels per K step
+#define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R, 4>(k, s)
+        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        return;
+    }
     if (k.terms == 1) {
 #define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R, 1>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)

@@ -68,7 +68,12 @@ constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 
 // BN x (WM x WN waves): 128 x (4x2) = 64x64 accumulator tiles per wave; 64 x (8x1) / 64 x (4x2) for 64-filter layers
 // TERMS: 3 = f16x3; 1 = half mode (hi halves of both operands only: no lo fragment reads, one MFMA per product block -
-// compile-time pruning of the same pinned slot plan); 2 = fp16 hi x hi + fp8 cross terms (own step: step8 below)
+// compile-time pruning of the same pinned slot plan); 2 = fp16 hi x hi + fp8 cross terms (own step: step8 below);
+// 4 = half mode with 64 channels per K step: the LDS rows (window and filter stages alike) are GATHERED by the DMA from the hi halves
+// of two consecutive 32-channel groups (a DMA lane's global address is free), [hi of group 2q | hi of group 2q+1], so the "lo" fragment
+// slots hold the second group's hi values and the step does A_hi x B_hi + A_lo x B_lo - the same DMA instructions, fragment reads and
+// barrier per step as TERMS = 1 for twice the channels, i.e. half the steps (a K step is bound by those, not by its MFMAs, once two
+// thirds of them are gone: profiles/r03_fp8_cross.txt #5).  Needs Cin % 64 == 0; the tensors in HBM stay H16.
 template <int BN, int WM, int WN, int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows, int nbuf) {
     static_assert(WM * WN == NW, "eight waves");
@@ -95,7 +100,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     unsigned long long clk_c0 = 0, clk_w0 = 0;
     if (clk_sample) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = wall_clock64(); }
 
-    const int W = p.W, G = p.Cin / 32;
+    const int W = p.W, G = TERMS == 4 ? p.Cin / 64 : p.Cin / 32;       // channel groups per K step
+    constexpr int GROUP_BYTES = TERMS == 4 ? 256 : 128;
+    // logical 16-byte chunk c of an LDS row -> chunk of the global record(s): TERMS = 4 takes chunks 0-3 (the hi halves) of two records
+    auto gchunk = [&](int c) { return TERMS == 4 ? ((c >> 2) << 3) + (c & 3) : c; };
     const int drow = lane >> 3, dpos = lane & 7;
     // window pieces: piece pc covers window rows pc*8 .. pc*8+7, wave w issues pieces w, w+8, ...; row j <-> flat input
     // pixel m0 - W - 1 + j (clamped into the tensor: rows outside it are never read unmasked); offsets in 16-byte units
@@ -104,19 +112,19 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 #pragma unroll
     for (int b = 0; b < B_INST; ++b) {
         const int row = (b * NW + wave) * 8 + drow;
-        w_off16[b] = (unsigned)min(n0 + row, p.Cout - 1) * (unsigned)(p.Kpad / 4) + (unsigned)(dpos ^ ((row >> 1) & 7));
+        w_off16[b] = (unsigned)min(n0 + row, p.Cout - 1) * (unsigned)(p.Kpad / 4) + (unsigned)gchunk(dpos ^ ((row >> 1) & 7));
     }
     const char *x_bytes = reinterpret_cast<const char *>(p.x), *w_bytes = reinterpret_cast<const char *>(TERMS == 2 ? p.w8 : (const void *)p.w);
     auto a_piece = [&](int g, int k) {                           // window of channel group g -> buffer g & 1
         const int pc = min(k * NW + wave, npieces - 1);        // surplus instructions repeat the last piece (same data, same place)
         const int j = pc * 8 + drow;
         const int f = min(max(m0 - W - 1 + j, 0), p.M - 1);
-        const unsigned off16 = (unsigned)f * (unsigned)(p.ldx / 4) + (unsigned)(dpos ^ ((j >> 1) & 7));
-        const char *src = x_bytes + (size_t)g * 128 + ((size_t)off16 << 4);
+        const unsigned off16 = (unsigned)f * (unsigned)(p.ldx / 4) + (unsigned)gchunk(dpos ^ ((j >> 1) & 7));
+        const char *src = x_bytes + (size_t)g * GROUP_BYTES + ((size_t)off16 << 4);
         __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(smem + (g & 1) * WB + pc * 8 * ROW), 16, 0, 0);
     };
     auto b_piece = [&](int g, int tap, int stage, int b) {       // filter rows of K chunk (tap, g)
-        const char *src = w_bytes + (size_t)(tap * G + g) * 128 + ((size_t)w_off16[b] << 4);
+        const char *src = w_bytes + (size_t)(tap * G + g) * GROUP_BYTES + ((size_t)w_off16[b] << 4);
         __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(bring + stage * B_STAGE + (b * NW + wave) * 8 * ROW), 16, 0, 0);
     };
 
@@ -186,6 +194,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
         if (YDS_WIN_ABL == 3) { acc1[i][j][term] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3]; return; }
+        if (TERMS == 4) {                                        // both slots hold hi values (of two channel groups)
+            if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
+            else if (term == 1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, acc1[i][j], 0, 0, 0);
+            return;
+        }
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
         else if (term == 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[i][j], 0, 0, 0);
         else acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[i][j], 0, 0, 0);
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
 
 template <int BN, int WM, int WN, int ACT, int RES, int TERMS = 3> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
-    const int wrows = window_rows(k.W), nbuf = k.Cin == 32 ? 1 : 2;
+    const int wrows = window_rows(k.W), nbuf = k.Cin == (TERMS == 4 ? 64 : 32) ? 1 : 2;
     // (the epilogue stages the whole 256 x BN tile in the same LDS: narrow images need more than their windows + ring)
     const size_t smem = std::max((size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW, conv_stage_bytes(BM, BN));
     static size_t attr_set = 0;
@@ -497,6 +510,16 @@ void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
 #undef YDS_CALL
         } else {
 #define YDS_CALL(A, R) launch_inst_win<64, 4, 2, A, R, 2>(k, s)
+            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        }
+    } else if (k.terms == 1 && k.Cin % 64 == 0 && !getenv("YDS_HALF_NARROW")) {   // half mode, 64 channels per step (YDS_HALF_NARROW: tuning aid, the 32-channel form)
+        if (shape == 0) {
+#define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R, 4>(k, s)
+            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
+#undef YDS_CALL
+        } else {
+#define YDS_CALL(A, R) launch_inst_win<64, 4, 2, A, R, 4>(k, s)
             YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
         }
