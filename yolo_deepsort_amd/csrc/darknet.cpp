@@ -943,6 +943,7 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     }
     a.w = wt.p; a.w16 = wt16.p; a.w16x = wt16x.p; a.w8_shift = w8_shift; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
     if (with_residual) { a.res = View{r.p, n, ho, wo, cout, ldy, a.y.fmt}; a.res_mode = RES_AFTER_ACT; }
+    if (const char *t = getenv("YDS_BENCH_TERMS")) a.terms = atoi(t) == 1 ? 1 : 3;      // tuning aid: the half-mode kernels on single layers
     hipStream_t st;
     YDS_HIP(hipStreamCreate(&st));
     hipEvent_t e0, e1;
