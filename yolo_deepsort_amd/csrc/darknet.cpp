@@ -671,7 +671,8 @@ void Darknet::forward_tiles_host(const uint8_t *frame, int h, int w, const int *
 
 bool Darknet::stem_fused(int batch) {
     static const bool off = getenv("YDS_NO_STEM_FUSE") != nullptr;
-    if (off || half_mode || !stem_fusable || conv_math() != MATH_F16X3 || !layers[0].loaded || !layers[1].loaded) return false;
+    // (half mode keeps the fused kernels: they compute the first layers in the default arithmetic, which half mode does anyway)
+    if (off || !stem_fusable || conv_math() != MATH_F16X3 || !layers[0].loaded || !layers[1].loaded) return false;
     if (stem_checked != batch) {
         ConvArgs a0 = conv_args(0, batch), a1 = conv_args(1, batch);
         stem_ok = a1.w16 && a1.y.fmt == FMT_H16 && conv_stem2_applicable(make_conv_args(a0), make_conv_args(a1));
@@ -682,7 +683,7 @@ bool Darknet::stem_fused(int batch) {
 
 bool Darknet::block1_fused(int batch) {
     static const bool off = getenv("YDS_NO_BLOCK_FUSE") != nullptr;
-    if (off || half_mode || block1_at < 0 || conv_math() != MATH_F16X3 || !layers[block1_at].loaded || !layers[block1_at + 1].loaded) return false;
+    if (off || block1_at < 0 || conv_math() != MATH_F16X3 || !layers[block1_at].loaded || !layers[block1_at + 1].loaded) return false;
     if (block1_checked != batch) {
         ConvArgs a2 = conv_args(block1_at, batch), a3 = conv_args(block1_at + 1, batch);
         block1_ok = a2.w16 && a3.w16 && conv_block1_applicable(make_conv_args(a2), make_conv_args(a3));
