@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")
+    ap.add_argument("--cross8-detector-only", action="store_true", help="with --cross8: the ReID network keeps the default arithmetic (track ids of crowd scenes unchanged)")
     ap.add_argument("--cross8", action="store_true", help="opt-in tier: the window 3x3 kernel computes the cross terms of the f16x3 product in fp8 e4m3 "
                                                           "(models.set_conv_cross8; not the metric's arithmetic: heads move by ~1e-5 of their maximum)")
     args = ap.parse_args()
@@ -140,7 +141,7 @@ def main():
 
     B, K, W = args.batch, args.steps, args.warmup
     if args.cross8:
-        _lib.check(lib.yds_set_conv_cross8(1))
+        _lib.check(lib.yds_set_conv_cross8(2 if args.cross8_detector_only else 1))
     wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
     cfg = wl.cfg
     wl.to_device()

@@ -437,7 +437,7 @@ def test_cross8_mode_detector_vs_oracle():
     x = np.random.RandomState(11).uniform(0, 1, (2, 3, 608, 608)).astype(F32)
     # (at this small batch the planner's timing would pick other kernels for most 3x3 layers: pin the window kernel where it applies)
     os.environ["YDS_CONV_FORCE"] = str(win)
-    prev = models.get_conv_cross8()                          # (YDS_CONV_CROSS8=1 runs of the whole suite)
+    prev = lib.yds_get_conv_cross8()                         # (YDS_CONV_CROSS8=1 runs of the whole suite)
     try:
         models.set_conv_cross8(False)
         full = np.asarray(net(x))
@@ -446,7 +446,7 @@ def test_cross8_mode_detector_vs_oracle():
         models.set_conv_cross8(False)
         again = np.asarray(net(x))
     finally:
-        models.set_conv_cross8(prev)
+        lib.yds_set_conv_cross8(prev)
         del os.environ["YDS_CONV_FORCE"]
     assert np.array_equal(full, again)
     want = ref(x[:1])

@@ -282,14 +282,18 @@ int conv_math() {
 }
 void set_conv_math(int m) { g_math = m == MATH_F32 ? MATH_F32 : MATH_F16X3; }
 static int g_cross8 = -1;
-bool conv_cross8() {
+static int cross8_mode() {
     if (g_cross8 < 0) {
         const char *e = getenv("YDS_CONV_CROSS8");
-        g_cross8 = e && atoi(e) != 0 ? 1 : 0;
+        const int v = e ? atoi(e) : 0;
+        g_cross8 = v == 1 || v == 2 ? v : 0;
     }
-    return g_cross8 == 1;
+    return g_cross8;
 }
-void set_conv_cross8(bool on) { g_cross8 = on ? 1 : 0; }
+bool conv_cross8() { return cross8_mode() != 0; }
+bool conv_cross8_reid() { return cross8_mode() == 1; }
+void set_conv_cross8(int mode) { g_cross8 = mode == 1 || mode == 2 ? mode : 0; }
+int get_conv_cross8() { return cross8_mode(); }
 
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
     ConvKernelArgs k = make_conv_args(a);

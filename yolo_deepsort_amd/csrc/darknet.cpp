@@ -899,8 +899,8 @@ const char *yds_conv_variant_name(int v) { return yds::conv_variant_name(v); }
 int yds_conv_num_variants(void) { return yds::kConvVariants; }
 int yds_set_conv_math(int mode) { yds::set_conv_math(mode); return 0; }
 int yds_get_conv_math(void) { return yds::conv_math(); }
-int yds_set_conv_cross8(int on) { yds::set_conv_cross8(on != 0); return 0; }
-int yds_get_conv_cross8(void) { return yds::conv_cross8() ? 1 : 0; }
+int yds_set_conv_cross8(int mode) { yds::set_conv_cross8(mode); return 0; }
+int yds_get_conv_cross8(void) { return yds::get_conv_cross8(); }
 int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual, int iters, double *avg_us,
                    int *variant) {
     YDS_API_BEGIN
