@@ -12,6 +12,8 @@
 // All kernels are one-element(-vector)-per-thread streaming kernels with 16-byte accesses where the
 // layout allows; grids are capped and grid-strided.
 #include "common.h"
+
+#include <algorithm>
 #include "h16.h"
 
 namespace yds {
@@ -200,26 +202,35 @@ struct YoloParams {
     float s0, s1;         // (img_h / H, img_w / W); quirk: x uses s0, y uses s1 (models.py:169-172,216)
 };
 
+// One wavefront per grid cell: the cell -> (row, column) arithmetic is done once per cell on the scalar side instead of three
+// integer divisions per value (round 3: the per-value form was ALU bound, 175 us per 16-frame pass; the values themselves are
+// computed by the same expressions).  The A x (5 + C) values of a cell are contiguous in the head tensor: lanes cover them 64 at
+// a time (255 values = four full sweeps), every anchor's row of the output is written contiguously.
 __global__ void yolo_decode_kernel(const float *head, float *out, int N, int H, int W, int ld, int A, int attrs, int total_boxes,
                                    int box_off, YoloParams yp) {
-    // one image per blockIdx.y, 32-bit index arithmetic inside it (an image has at most a few million values)
-    const int HW = H * W, n = blockIdx.y;
-    const unsigned per_img = (unsigned)A * HW * attrs;
+    const int HW = H * W, n = blockIdx.y, per_cell = A * attrs;
     (void)N;
-    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < per_img; idx += gridDim.x * blockDim.x) {
-        const unsigned b = idx / (unsigned)attrs;
-        const int t = idx - b * attrs;
-        const int box = b;
-        const int a = box / HW, cell = box - a * HW;
+    const int lane = threadIdx.x & 63;
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    for (int cell = wave0; cell < HW; cell += nwaves) {
         const int gy = cell / W, gx = cell - gy * W;
-        float v = head[((size_t)(n * H + gy) * W + gx) * ld + a * attrs + t];
-        float r;
-        if (t == 0) r = __fmul_rn(__fadd_rn(1.f / (1.f + expf(-v)), (float)gx), yp.s0);
-        else if (t == 1) r = __fmul_rn(__fadd_rn(1.f / (1.f + expf(-v)), (float)gy), yp.s1);
-        else if (t == 2) r = __fmul_rn(__fmul_rn(expf(v), yp.aw[a]), yp.s0);
-        else if (t == 3) r = __fmul_rn(__fmul_rn(expf(v), yp.ah[a]), yp.s1);
-        else r = 1.f / (1.f + expf(-v));
-        out[((size_t)n * total_boxes + box_off + box) * attrs + t] = r;
+        const float *src = head + ((size_t)(n * H + gy) * W + gx) * ld;
+        float *dst = out + ((size_t)n * total_boxes + box_off + cell) * attrs;
+        for (int i = lane; i < per_cell; i += 64) {
+            int a = 0;
+#pragma unroll
+            for (int k = 1; k < 8; ++k) a += (k < A && i >= k * attrs) ? 1 : 0;
+            const int t = i - a * attrs;
+            const float v = src[i];
+            float r;
+            if (t == 0) r = __fmul_rn(__fadd_rn(1.f / (1.f + expf(-v)), (float)gx), yp.s0);
+            else if (t == 1) r = __fmul_rn(__fadd_rn(1.f / (1.f + expf(-v)), (float)gy), yp.s1);
+            else if (t == 2) r = __fmul_rn(__fmul_rn(expf(v), yp.aw[a]), yp.s0);
+            else if (t == 3) r = __fmul_rn(__fmul_rn(expf(v), yp.ah[a]), yp.s1);
+            else r = 1.f / (1.f + expf(-v));
+            dst[(size_t)a * HW * attrs + t] = r;                    // box = a * HW + cell
+        }
     }
 }
 
@@ -237,7 +248,8 @@ void launch_yolo_decode(const View &head, float *out, int total_boxes, int box_o
     if (head.c != A * attrs) fail("yolo: head has %d channels, expected %d", head.c, A * attrs);
     const size_t per_img = (size_t)A * head.h * head.w * attrs;
     if (per_img >= (1ull << 31)) fail("yolo: head too large for 32-bit indexing");
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3((unsigned)((per_img + 255) / 256), head.n), dim3(256), 0, s, head.p, out, head.n, head.h, head.w,
+    const unsigned cells = (unsigned)head.h * head.w;                   // four wavefronts per workgroup, a few cells per wavefront
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(std::min((cells + 3) / 4, 2048u), head.n), dim3(256), 0, s, head.p, out, head.n, head.h, head.w,
                        head.ld, A, attrs, total_boxes, box_off, yp);
     YDS_HIP(hipGetLastError());
 }
