@@ -15,10 +15,13 @@ Rank 0 prints ONE JSON line:
                       video_detect.py:124-157); value_frame_by_frame_lookahead1 hands the next frame over one step early
   roofline            dominant conv kernel vs its MFMA bound: HIP event pairs around every conv launch on the detector's
                       stream, recorded (without host synchronisation) over a repeat of the SAME K timed steps - ReID and
-                      association streams live, next pass prefetched - so `frac` is the overlapped, in-pipeline figure;
-                      `frac_isolated` comes from two non-prefetched steps (conv stream alone).  `all_conv_kernels` adds the
-                      per-launch attainable bound max(flops / MFMA peak, bytes / 6.29 TB/s) so HBM-bound 1x1 layers are
-                      priced against the right roof.
+                      association streams live, next pass prefetched - so `achieved`, `avg_launch_us` and `frac` are the
+                      in-pipeline figures `value` was measured under (what a rocprofv3 --kernel-trace --stats summary of this
+                      command shows: profiles/); `frac_isolated` / `achieved_isolated` come from two non-prefetched steps (conv
+                      stream alone).  `all_conv_kernels` adds the per-launch attainable bound max(flops / MFMA peak,
+                      bytes / 6.29 TB/s) so HBM-bound 1x1 layers are priced against the right roof.
+  roofline_f32        the same record for the value_f32_math leg (exact fp32 MFMA kernels, the reference's own arithmetic)
+                      against the fp32-input MFMA peak of 157.3 TFLOP/s
   cpu_baseline        the oracle pipeline (C + OpenMP / BLAS) on the host cores over a bounded sample of the same stream
 N > 1: every rank runs its own stream (cfg4 = cfg3 per rank, seeds = rank); after each step the ranks all-gather their
 result rows ({count, rows[256][6]} per frame, RCCL through libydsort's yds_comm_*) so rank 0 holds every stream's output.
@@ -52,7 +55,7 @@ def cpu_baseline(config, n_frames):
     return rec
 
 
-def timed_steps(wl, ranks, sync, K, W, first, host_frames, lookahead=True, keep=None):
+def timed_steps(wl, ranks, sync, K, W, first, host_frames, lookahead=True, keep=None, own=None):
     """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync; max over ranks.
     Every step ends with the exchange step of the multi-GPU run: the all-gather of this batch's result rows (no-op for one rank)."""
     for i in range(first, first + W):
@@ -69,12 +72,14 @@ def timed_steps(wl, ranks, sync, K, W, first, host_frames, lookahead=True, keep=
         if keep is not None:
             keep.append(streams)
     sync()
+    if own is not None:
+        own["dt"] = time.perf_counter() - t0        # this rank's own K steps (before the closing barrier)
     ranks.barrier()
     sync()
     return ranks.max_over_ranks(time.perf_counter() - t0), n_out
 
 
-def conv_roofline(variants, peak, args_half):
+def conv_roofline(variants, peak):
     """Per-variant totals -> the dominant variant's record + the all-conv record (achieved, frac, frac_of_attainable)."""
     live = [v for v in variants if v["launches"]]
     if not live:
@@ -93,6 +98,77 @@ def conv_roofline(variants, peak, args_half):
     return rec, allc
 
 
+def measure_roofline(wl, ranks, sync, pl, K, W, first, peak, peak_of=None):
+    """Event-timed conv launches of the detector stream (yds_conv_timing_ex: a HIP event pair around every launch, resolved when the
+    counters are read - no host synchronisation inside a pass).
+      in-pipeline: a repeat of the K timed steps (prefetched, ReID / association streams live) - what `value` ran under;
+      isolated:    two non-prefetched steps (the conv stream alone, launches back to back).
+    Returns (in-pipeline variants, record of the kernel that dominates IN the pipeline, all-conv record, seconds of the repeat);
+    the record carries the same kernel's isolated figures.  peak_of(kernel name) -> that kernel's own bound, if it differs."""
+    pl.conv_timing(wl.net, 1)
+    dt_ev, _ = timed_steps(wl, ranks, sync, K, W, first, host_frames=False)
+    variants = pl.conv_timing(wl.net, 2)
+    dom, allc = conv_roofline(variants, peak)
+    pl.conv_timing(wl.net, 1)
+    base = first + W + K
+    for i in range(base, base + 2):
+        wl.step(i, prefetch=False)
+    iso_variants = pl.conv_timing(wl.net, 2)
+    _, iso_all = conv_roofline(iso_variants, peak)
+    if dom is None:
+        return variants, None, None, dt_ev
+    dom_peak = peak_of(dom["kernel"]) if peak_of else peak
+    dom["peak"] = dom_peak
+    dom["frac"] = dom["achieved"] / dom_peak
+    iso = next((v for v in iso_variants if v["name"] == dom["kernel"] and v["launches"]), None)
+    dom["achieved_isolated"] = None if iso is None else iso["flops"] / iso["us"] / 1e6
+    dom["avg_launch_us_isolated"] = None if iso is None else iso["us"] / iso["launches"]
+    dom["frac_isolated"] = None if iso is None else dom["achieved_isolated"] / dom_peak
+    allc["isolated"] = iso_all
+    allc["steps_in_pipeline"] = K + W
+    return variants, dom, allc, dt_ev
+
+
+def roofline_json(dom, allc, B, peak_note, traffic=None):
+    """The `roofline` object of the JSON line (bench contract: bound / achieved / peak / unit / frac / traffic + detail)."""
+    r = lambda v, n=4: None if v is None else round(v, n)
+    iso = allc["isolated"]
+    rec = dict(bound="mfma", kernel=dom["kernel"], achieved=r(dom["achieved"], 2), peak=r(dom["peak"], 1), unit="TFLOP/s", frac=r(dom["frac"]),
+               traffic=None,
+               timing="HIP event pairs around every conv launch on the detector stream, no host synchronisation inside a pass.  achieved / "
+                      "avg_launch_us / frac = IN THE PIPELINE: a repeat of the K timed steps (prefetched, ReID / association streams live) - the "
+                      "conditions `value` was measured under and what a rocprofv3 kernel-trace summary of this command shows; *_isolated = two "
+                      "non-prefetched steps (conv stream alone)",
+               avg_launch_us=r(dom["avg_launch_us"], 2), launches=dom["launches"],
+               achieved_isolated=r(dom["achieved_isolated"], 2), frac_isolated=r(dom["frac_isolated"]), avg_launch_us_isolated=r(dom["avg_launch_us_isolated"], 2),
+               peak_note=peak_note, frac_of_attainable=r(dom["frac_of_attainable"]),
+               flops_per_launch=dom["flops_per_launch"], algorithmic_bytes_per_launch=round(dom["bytes_per_launch"]),
+               share_of_conv_time=r(dom["share_of_conv_time"]),
+               all_conv_kernels=dict(achieved=r(allc["achieved"], 2), frac=r(allc["frac"]), frac_of_attainable=r(allc["frac_of_attainable"]),
+                                     us_per_frame=r(allc["measured_us"] / (allc["steps_in_pipeline"] * B), 1),
+                                     achieved_isolated=r(iso["achieved"], 2), frac_isolated=r(iso["frac"]),
+                                     frac_of_attainable_isolated=r(iso["frac_of_attainable"]), us_per_frame_isolated=r(iso["measured_us"] / (2 * B), 1),
+                                     algorithmic_hbm_tb_s_isolated=r(iso["hbm_tb_s"], 3),
+                                     attainable="sum over launches of max(flops / MFMA bound, algorithmic bytes / 6.29 TB/s)"))
+    if traffic:
+        rec.update(traffic)
+    return rec
+
+
+def committed_traffic(config, kernel, B, mode=""):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this command (tools/profile_bench.sh PMC=1): PMC
+    counters cannot be read from inside this process."""
+    cfg_key = "cfg3" if config == "cfg4" else config
+    for rnd in ("r04", "r03", "r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{cfg_key}{mode}.json")
+        if os.path.exists(tpath) and B == 16:
+            rec = json.load(open(tpath))["kernels"].get(kernel)
+            if rec:
+                return dict(traffic=round(rec["hbm_bytes_per_launch"]),
+                            traffic_unit="bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/" + os.path.basename(tpath) + ")")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +185,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")
     ap.add_argument("--cross8-detector-only", action="store_true", help="with --cross8: the ReID network keeps the default arithmetic (track ids of crowd scenes unchanged)")
+    ap.add_argument("--math", default="f16x3", choices=["f16x3", "f32"], help="conv arithmetic of the WHOLE run: f16x3 (default: split-fp16 operands, exact products, "
+                                                                              "fp32 accumulate) or f32 (exact fp32 MFMA kernels; profiles of the value_f32_math leg)")
+    ap.add_argument("--value-cross8", action="store_true", help="add a short leg in the opt-in cross8 tier (detector only) and report it as value_cross8")
     ap.add_argument("--cross8", action="store_true", help="opt-in tier: the window 3x3 kernel computes the cross terms of the f16x3 product in fp8 e4m3 "
                                                           "(models.set_conv_cross8; not the metric's arithmetic: heads move by ~1e-5 of their maximum)")
     args = ap.parse_args()
@@ -140,6 +219,15 @@ def main():
     ranks.connect()                # RCCL communicator on the bound device (N > 1)
 
     B, K, W = args.batch, args.steps, args.warmup
+    # A multi-GPU run must not go green on the host transport by accident: RCCL is what the N > 1 numbers are about.
+    if world > 1 and ranks.requested == "nccl" and ranks.transport != "rccl":
+        if rank == 0:
+            print(json.dumps({"error": "bench.py --gpus %d: the RCCL communicator could not be formed (%s); refusing to measure over gloo - "
+                                       "set YDS_DIST_BACKEND=gloo to run the host transport on purpose" % (world, ranks.fallback_reason)}))
+        ranks.shutdown()
+        raise SystemExit(3)
+    if args.math == "f32":
+        lib.yds_set_conv_math(0)
     if args.cross8:
         _lib.check(lib.yds_set_conv_cross8(2 if args.cross8_detector_only else 1))
     wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
@@ -152,7 +240,9 @@ def main():
     # ---- the metric: frames resident in HBM
     pl.conv_clock(reset=True)
     kept = [] if args.dump_rows else None
-    dt, n_out = timed_steps(wl, ranks, sync, K, W, 0, host_frames=False, keep=kept)     # n_out: rows of ALL streams (gathered on every rank)
+    own = {}
+    dt, n_out = timed_steps(wl, ranks, sync, K, W, 0, host_frames=False, keep=kept, own=own)     # n_out: rows of ALL streams (gathered on every rank)
+    dt_own = own["dt"]
     clock_ghz, clock_ms = pl.conv_clock(reset=True)              # shader clock inside the window kernels over the K timed steps (+ warm-up)
     if kept is not None and rank == 0:
         import numpy as np
@@ -163,9 +253,12 @@ def main():
                     arrays[f"s{st}_k{k}_f{f}"] = np.full((1, 6), -1, np.int32) if o is None else np.asarray(o, np.int32).reshape(-1, 6)
         np.savez(args.dump_rows, **arrays)
     rank_devices = ranks.gather_objects((_lib.current_device(), _lib.pci_bus_id()))
+    rank_values = ranks.gather_objects(round(K * B / dt_own, 2))        # every rank's own frames/s over its own clock around the K steps
     flops_frame = wl.flops_per_frame()
     stage = wl.pipe.stage_us()
     math_name = {0: "f32", 1: "f16x3", 2: "f16"}[lib.yds_get_conv_math()] if not args.half else "f16"
+    # dtype: the arithmetic type the conv path computes in.  f16x3 = both operands as two-term fp16 expansions (22 significant bits), exact
+    # fp16 products, fp32 accumulation - the reference's fp32 class; f32 = v_mfma_f32_32x32x2_f32
     if args.cross8 and math_name == "f16x3":
         math_name = "f16x3, window 3x3 kernel: fp16 hi x hi + fp8 e4m3 cross terms"
 
@@ -175,85 +268,37 @@ def main():
         dt_up, _ = timed_steps(wl, ranks, sync, K, W, W + K, host_frames=True)
 
     roofline, variants = None, None
-    frames_total_for_frac = K * B                               # per rank (the roofline is reported for rank 0's GPU)
     if not args.no_roofline:
         # (every rank runs the leg - its steps contain the exchange step - rank 0 reports)
         f16x3 = lib.yds_get_conv_math() == 1 and not args.half
         peak = PEAK_F16_MFMA_TFLOPS / 3 if f16x3 else (PEAK_F16_MFMA_TFLOPS if args.half else PEAK_F32_MFMA_TFLOPS)
-        # (a) the SAME K timed steps once more with an event pair around every conv launch (no host sync inside the pass)
-        pl.conv_timing(wl.net, 1)
-        dt_ev, _ = timed_steps(wl, ranks, sync, K, W, 2 * (W + K), host_frames=False)
-        variants = pl.conv_timing(wl.net, 2)
-        dom, allc = conv_roofline(variants, peak, args.half)
-        # (b) two non-prefetched steps: the conv stream alone (ReID / association of a step run after its detector pass)
-        pl.conv_timing(wl.net, 1)
-        base = 3 * (W + K)
-        for i in range(base, base + 2):
-            wl.step(i, prefetch=False)
-        iso_variants = pl.conv_timing(wl.net, 2)
-        iso_dom, iso_all = conv_roofline(iso_variants, peak, args.half)
-        if rank == 0 and iso_dom is not None:
-            # `frac` = the kernel on its own stream with nothing else resident (two non-prefetched steps, launches back to back at
-            # sustained clocks); `frac_overlapped` = the same kernel inside the timed pipeline, where the ReID network's convolutions
-            # (a third of the conv FLOPs, not counted here) share the CUs from a second stream during part of every detector pass
-            ov_same = next((v for v in variants if v["name"] == iso_dom["kernel"] and v["launches"]), None)
-            dom_ov, dom = dom, iso_dom
-            peak_all = peak
-            if args.cross8 and f16x3 and dom["kernel"].startswith("conv3x3_f16x3_win<256,128"):
-                # the dominant kernel's own bound in this mode: 128 instead of 192 pipe cycles per 32 channels and accumulator tile
-                peak = PEAK_F16_MFMA_TFLOPS / 2
-                dom["frac"] = dom["achieved"] / peak
-            roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(dom["achieved"], 2), peak=round(peak, 1),
-                            unit="TFLOP/s", frac=round(dom["frac"], 4), traffic=None,
-                            timing="HIP event pairs around every conv launch on the detector stream, no host synchronisation inside a pass: "
-                                   "frac = two non-prefetched steps (conv stream alone); frac_overlapped = a repeat of the K timed steps "
-                                   "(prefetched, ReID / association streams live)",
-                            frac_overlapped=None if ov_same is None else round(ov_same["flops"] / ov_same["us"] / 1e6 / peak, 4),
-                            dominant_kernel_overlapped=dom_ov["kernel"],
-                            peak_note=("cross8: two fp16 MFMAs + one fp8 K=64 MFMA per 32 channels = 2500 / 2 TFLOP/s fp32-equivalent (the other kernels: 2500 / 3)"
-                                       if args.cross8 and peak != peak_all else
-                                       "dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
-                                       else ("dense fp16 MFMA" if args.half else "fp32-input MFMA, 64 FLOP/clk/SIMD")),
-                            frac_of_fp32_mfma_peak=round(dom["achieved"] / PEAK_F32_MFMA_TFLOPS, 4),
-                            # pure-MFMA loop on random fp16 data, sustained (power limited): profiles/r01_ablation_dma.txt #6
-                            frac_of_measured_mfma_ceiling=round(dom["achieved"] / (MEASURED_F16_MFMA_TFLOPS / 3 if f16x3 else PEAK_F32_MFMA_TFLOPS), 4),
-                            frac_of_attainable=round(dom["frac_of_attainable"], 4),
-                            avg_launch_us=round(dom["avg_launch_us"], 2), launches=dom["launches"],
-                            flops_per_launch=dom["flops_per_launch"], algorithmic_bytes_per_launch=round(dom["bytes_per_launch"]),
-                            share_of_conv_time=round(dom["share_of_conv_time"], 4),
-                            fps_with_conv_events=round(ranks.total_frames(K, B) / dt_ev, 2),
-                            all_conv_kernels=dict(achieved=round(iso_all["achieved"], 2), frac=round(iso_all["frac"], 4),
-                                                  frac_overlapped=round(allc["frac"], 4),
-                                                  algorithmic_hbm_tb_s=round(iso_all["hbm_tb_s"], 3),
-                                                  attainable="sum over launches of max(flops / MFMA bound, algorithmic bytes / 6.29 TB/s)",
-                                                  frac_of_attainable=round(iso_all["frac_of_attainable"], 4),
-                                                  frac_of_attainable_overlapped=round(allc["frac_of_attainable"], 4),
-                                                  us_per_frame=round(iso_all["measured_us"] / (2 * B), 1),
-                                                  us_per_frame_overlapped=round(allc["measured_us"] / ((K + W) * B), 1)),
-                            # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
-                            # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
-                            pipeline_conv_frac=round(flops_frame * frames_total_for_frac / dt / 1e12 / peak_all, 4),
-                            # the peak assumes 2.4 GHz; the chip is power limited under this load: clock sampled INSIDE the window
-                            # kernels (s_memtime / s_memrealtime, one workgroup in 32) over the timed region
-                            sustained_clock_ghz=round(clock_ghz, 3), nominal_clock_ghz=2.4,
-                            peak_at_sustained_clock=round(peak * clock_ghz / 2.4, 1) if clock_ghz else None,
-                            frac_at_sustained_clock=round(dom["achieved"] / (peak * clock_ghz / 2.4), 4) if clock_ghz else None)
-            # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process; they come from
-            # the committed rocprofv3 --pmc passes over this same command (tools/profile_bench.sh, PMC=1)
-            for rnd in ("r03", "r02", "r01"):
-                cfg_key = "cfg3" if args.config == "cfg4" else args.config
-                tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{cfg_key}.json")
-                if os.path.exists(tpath) and B == 16:
-                    rec = json.load(open(tpath))["kernels"].get(dom["kernel"])
-                    if rec:
-                        roofline["traffic"] = round(rec["hbm_bytes_per_launch"])
-                        roofline["traffic_unit"] = "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/" + os.path.basename(tpath) + ")"
-                        break
+        x8 = args.cross8 and f16x3
+        # cross8: the window kernel's own bound is 128 instead of 192 pipe cycles per 32 channels and accumulator tile
+        peak_of = (lambda name: PEAK_F16_MFMA_TFLOPS / 2 if x8 and name.startswith("conv3x3_f16x3_win<256,128") else peak)
+        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, 2 * (W + K), peak, peak_of)
+        if rank == 0 and dom is not None:
+            note = ("cross8: two fp16 MFMAs + one fp8 K=64 MFMA per 32 channels = 2500 / 2 TFLOP/s fp32-equivalent (the other kernels: 2500 / 3)"
+                    if dom["peak"] != peak else "dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
+                    else ("dense fp16 MFMA" if args.half else "fp32-input MFMA, 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz"))
+            roofline = roofline_json(dom, allc, B, note, committed_traffic(args.config, dom["kernel"], B, "_f32" if math_name == "f32" else ""))
+            roofline.update(
+                frac_of_fp32_mfma_peak=round(dom["achieved"] / PEAK_F32_MFMA_TFLOPS, 4),
+                # pure-MFMA loop on random fp16 data, sustained (power limited): profiles/r01_ablation_dma.txt #6
+                frac_of_measured_mfma_ceiling=round(dom["achieved"] / (MEASURED_F16_MFMA_TFLOPS / 3 if f16x3 else PEAK_F32_MFMA_TFLOPS), 4),
+                fps_with_conv_events=round(ranks.total_frames(K, B) / dt_ev, 2),
+                # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
+                # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
+                pipeline_conv_frac=round(flops_frame * K * B / dt / 1e12 / peak, 4),
+                # the peak assumes 2.4 GHz; the chip is power limited under this load: clock sampled INSIDE the window
+                # kernels (s_memtime / s_memrealtime, one workgroup in 32) over the timed region
+                sustained_clock_ghz=round(clock_ghz, 3), nominal_clock_ghz=2.4,
+                peak_at_sustained_clock=round(dom["peak"] * clock_ghz / 2.4, 1) if clock_ghz else None,
+                frac_at_sustained_clock=round(dom["achieved"] / (dom["peak"] * clock_ghz / 2.4), 4) if clock_ghz else None)
 
     # ---- power experiment: the dominant layer alone, random operands vs operands that never toggle (same binary, same instruction
     #      stream; the chip is power limited)
     power = None
-    if rank == 0 and not args.no_roofline and not args.half:
+    if rank == 0 and not args.no_roofline and not args.half and math_name != "f32":
         import ctypes as C
         shape = (76, 76, 128, 256, 3, 1, 1, 0)
         rec = {}
@@ -281,9 +326,10 @@ def main():
         del wl1
         sync()
 
-    # ---- exact-fp32 kernels, short run (the network is re-planned: tensor formats depend on the conv math)
-    f32_fps = None
-    if not args.no_extras and not args.half:
+    # ---- exact-fp32 kernels (the reference's own arithmetic), short run; the network is re-planned: tensor formats depend on the
+    #      conv math.  Its roofline block is measured like the default one, against the fp32-input MFMA peak.
+    f32_fps, roofline_f32, value_cross8 = None, None, None
+    if not args.no_extras and not args.half and math_name != "f32":
         del wl
         sync()
         lib.yds_set_conv_math(0)
@@ -292,8 +338,25 @@ def main():
         k32 = max(3, min(K, 6))
         dt32, _ = timed_steps(wl32, ranks, sync, k32, 2, 0, host_frames=False)
         f32_fps = ranks.total_frames(k32, B) / dt32
+        if not args.no_roofline:
+            _, dom32, all32, _ = measure_roofline(wl32, ranks, sync, pl, k32, 2, k32 + 2, PEAK_F32_MFMA_TFLOPS)
+            if rank == 0 and dom32 is not None:
+                roofline_f32 = roofline_json(dom32, all32, B, "fp32-input MFMA (v_mfma_f32_32x32x2_f32), 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz",
+                                             committed_traffic(args.config, dom32["kernel"], B, "_f32"))
+                roofline_f32["pipeline_conv_frac"] = round(flops_frame * k32 * B / dt32 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                roofline_f32["value_f32_math"] = round(f32_fps, 2)
         del wl32
         lib.yds_set_conv_math(1)
+        # ---- the opt-in cross8 tier (detector only: the ReID network keeps the default arithmetic, so features and track ids are
+        #      those of the default mode; tests/test_gpu_bench_shape.py runs the parity test in this mode) - reported, never `value`
+        if args.value_cross8 and not args.cross8:
+            _lib.check(lib.yds_set_conv_cross8(2))
+            wlx = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base))
+            wlx.to_device()
+            dtx, _ = timed_steps(wlx, ranks, sync, k32, 2, 0, host_frames=False)
+            value_cross8 = ranks.total_frames(k32, B) / dtx
+            del wlx
+            _lib.check(lib.yds_set_conv_cross8(0))
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:      # rank 0 at N = 1 only (bench contract)
@@ -308,7 +371,8 @@ def main():
             "dtype": math_name, "data": "synthetic",
             "config": {"workload": cfg["workload"], "frames_per_step": B, "streams": world, "frame": "1920x1080x3 u8",
                        "frames_in": "resident in HBM", "tracker_rows_out": n_out, "parallelism": f"stream-per-gpu x{world}",
-                       "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices]},
+                       "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices],
+                       "rank_values": rank_values, **ranks.describe()},
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_with_upload is the PCIe-inclusive rate",
             "value_with_upload": None if dt_up is None else round(frames_total / dt_up, 2),
             "value_with_upload_note": "same K steps, frames handed over as pinned host memory and uploaded inside the timed region (copy stream, three staging buffers, each batch announced two steps ahead like a decoder queue)",
@@ -322,7 +386,10 @@ def main():
                 "RCCL via yds_comm_*" if ranks.comm is not None else ("gloo" + (f"; RCCL unavailable: {ranks.fallback_reason}" if ranks.fallback_reason else ""))),
             "stage_us_last_step": {k: round(v, 1) for k, v in stage.items()},
             "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
-            "roofline": roofline, "power_experiment": power, "conv_variants": variants, "cpu_baseline": cpu,
+            "value_cross8": None if value_cross8 is None else round(value_cross8, 2),
+            "value_cross8_note": "opt-in tier, detector only (models.set_conv_cross8(True, reid=False)): fp8 cross terms in the window 3x3 kernel, heads within 1e-3, "
+                                 "track ids those of the default mode; never the metric's arithmetic",
+            "roofline": roofline, "roofline_f32": roofline_f32, "power_experiment": power, "conv_variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     ranks.shutdown()

@@ -188,6 +188,7 @@ int yds_tracker_get_state(yds_trk *, int32_t *ids, int32_t *state, int32_t *tsu,
 int yds_tracker_gallery_rows(const yds_trk *);
 /* Track.payload of every live track, in track-list order (deep_sort/sort/track.py:77,141: the class id the demo passes) */
 int yds_tracker_get_payload(yds_trk *, float *payload, int cap);
+int yds_tracker_get_age(yds_trk *, int32_t *age, int cap);              /* Track.age (track.py:40,115), track-list order */
 int yds_tracker_last_unmatched(yds_trk *, int32_t *um_tracks, int cap_t, int *n_t,
                                int32_t *um_dets, int cap_d, int *n_d);
 /* stand-alone association primitives (parity tests call these through the C ABI) */
@@ -290,13 +291,18 @@ int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize,
  * rank 0 collecting every stream's int32 rows.  These entries run RCCL directly (ncclCommInitRank / ncclAllGather /
  * ncclAllReduce over xGMI) on the device bound by yds_init; librccl is opened lazily by yds_comm_unique_id /
  * yds_comm_create.  The launcher distributes the 128-byte id (rank 0 creates it) by any host-side channel.
- *   yds_comm_allgather_rows: per frame b of a batch the fixed block {int32 count; int32 rows[YDS_COMM_MAX_ROWS][6]}
- *     (count = counts_host[b], -1 = detector returned None) is gathered from every rank:
- *     all_host = int32 [world][batch][1 + YDS_COMM_MAX_ROWS*6], rank-major.
+ *   yds_comm_preflight: LOCAL, non-collective check (librccl and its symbols, bound device, stream) the ranks vote on over
+ *     their host group before any of them enters ncclCommInitRank (itself a collective).
+ *   yds_comm_allgather_rows: per frame b of a batch the block {int32 header; int32 rows[rows_per_block][6]} is gathered from
+ *     every rank: all_host = int32 [world][batch][1 + rows_per_block*6], rank-major.  header = counts_host[b] (-1 = detector
+ *     returned None), or -(2 + n) for a frame whose n rows exceed rows_per_block (not sent).  *rows_needed = the largest row
+ *     count any rank announced; when it exceeds rows_per_block every rank repeats the call with a larger block (the block
+ *     grows like every other capacity of the library; YDS_COMM_MIN_ROWS is the size to start from).
  *   yds_comm_allreduce_f64: in-place sum (op 0) / max (op 1) over ranks of n doubles (frame counters, the job time).
  *   yds_comm_barrier: every rank has arrived (an all-reduce of one element). */
 #define YDS_COMM_ID_BYTES 128
-#define YDS_COMM_MAX_ROWS 256
+#define YDS_COMM_MIN_ROWS 64
+int yds_comm_preflight(void);
 int yds_comm_unique_id(void *id128_out);
 yds_comm *yds_comm_create(const void *id128, int world, int rank);
 void yds_comm_destroy(yds_comm *);
@@ -305,7 +311,8 @@ int yds_comm_rank(const yds_comm *);
 int yds_comm_rccl_version(void);
 int yds_comm_allgather(yds_comm *, const void *send_host, size_t bytes, void *recv_host);
 int yds_comm_allgather_dev(yds_comm *, const void *send_dev, size_t bytes, void *recv_dev);
-int yds_comm_allgather_rows(yds_comm *, const int32_t *out6_host, int cap, const int32_t *counts_host, int batch, int32_t *all_host);
+int yds_comm_allgather_rows(yds_comm *, const int32_t *out6_host, int cap, const int32_t *counts_host, int batch, int rows_per_block,
+                            int32_t *all_host, int *rows_needed);
 int yds_comm_allreduce_f64(yds_comm *, double *vals_host, int n, int op);
 int yds_comm_barrier(yds_comm *);
 

@@ -14,6 +14,8 @@ import types
 import numpy as np
 
 REF_ROOT = "/root/reference"
+# path -> dict(frames=uint8 [N,H,W,3] BGR, fps=float, on_read=callable(t) | None): clips the FileVideoStream shim serves
+CLIPS = {}
 
 
 def available():
@@ -63,22 +65,87 @@ def install_shims():
         cv2.COLOR_RGB2BGR = 4
         cv2.COLOR_BGR2RGB = 4
         cv2.FONT_HERSHEY_SIMPLEX = 0
+        cv2.FONT_HERSHEY_COMPLEX_SMALL = 5
+        cv2.WINDOW_NORMAL = 0
+        # capture properties VideoDetector.detect queries (video_detect.py:91-101); served by the FileVideoStream shim below
+        cv2.CAP_PROP_POS_FRAMES, cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT = 1, 3, 4
+        cv2.CAP_PROP_FPS, cv2.CAP_PROP_FOURCC, cv2.CAP_PROP_FRAME_COUNT = 5, 6, 7
 
         def resize(img, size, interpolation=1):
             return resize_bilinear_u8(np.asarray(img), size)
         cv2.resize = resize
         cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[..., ::-1])
-        for name in ("rectangle", "putText", "imshow", "waitKey", "destroyAllWindows", "line", "circle"):
+        for name in ("rectangle", "putText", "imshow", "waitKey", "destroyAllWindows", "line", "circle", "namedWindow", "resizeWindow"):
             setattr(cv2, name, lambda *a, **k: None)
         cv2.getTextSize = lambda *a, **k: ((0, 0), 0)
+
+        class VideoWriter:                                       # video_detect.py:106,189,202: records what the generator wrote
+            written = []
+
+            def __init__(self, path, fourcc, fps, size):
+                self.args = (path, fourcc, fps, size)
+                VideoWriter.written.append(self)
+                self.frames = 0
+
+            def write(self, frame):
+                self.frames += 1
+
+            def release(self):
+                pass
+        cv2.VideoWriter = VideoWriter
         sys.modules["cv2"] = cv2
     if "imutils" not in sys.modules:
         im = types.ModuleType("imutils")
         vid = types.ModuleType("imutils.video")
 
-        class FileVideoStream:            # I/O only; never exercised by the fixtures
-            def __init__(self, *a, **k):
-                raise IOError("no video I/O in the oracle harness")
+        class _Capture:
+            """cv2.VideoCapture stand-in over an in-memory clip (the queries of video_detect.py:89-101)."""
+
+            def __init__(self, src):
+                self.src, self.pos = src, 0
+
+            def isOpened(self):
+                return True
+
+            def get(self, prop):
+                n, h, w = self.src["frames"].shape[:3]
+                return {5: self.src.get("fps", 25.0), 6: 0.0, 3: float(w), 4: float(h), 7: float(n), 1: float(self.pos)}[prop]
+
+            def set(self, prop, value):
+                assert prop == 1
+                self.pos = int(value)
+
+        class FileVideoStream:
+            """imutils.video.FileVideoStream stand-in: serves the BGR frames registered under `path` in CLIPS one by one on
+            the caller's thread (the real class decodes on a reader thread into a queue; the consumer-side protocol -
+            .stream, start(), more(), read() with the transform applied - is the same).  `on_read(t)` lets a fixture
+            script set per-frame state (the head-logit injection) right before the generator receives frame t."""
+
+            def __init__(self, path, transform=None, queue_size=128):
+                if path not in CLIPS:
+                    raise IOError("no clip registered for %r" % (path,))
+                self.src = CLIPS[path]
+                self.stream = _Capture(self.src)
+                self.transform = transform
+
+            def start(self):
+                return self
+
+            def more(self):
+                return self.stream.pos < len(self.src["frames"])
+
+            def read(self):
+                t = self.stream.pos
+                if t >= len(self.src["frames"]):
+                    return None
+                self.stream.pos += 1
+                if self.src.get("on_read") is not None:
+                    self.src["on_read"](t)
+                frame = np.array(self.src["frames"][t])
+                return self.transform(frame) if self.transform is not None else frame
+
+            def stop(self):
+                pass
         vid.FileVideoStream = FileVideoStream
         im.video = vid
         sys.modules.update({"imutils": im, "imutils.video": vid})
@@ -101,6 +168,7 @@ def import_reference():
     import yolo3.utils.model_build as model_build
     import yolo3.utils.parse_config as parse_config
     import yolo3.detect.img_detect as img_detect
+    import yolo3.detect.video_detect as video_detect
     import deep_sort.deep_sort as ds
     import deep_sort.deep.model as reid_model
     import deep_sort.deep.feature_extractor as fe
@@ -109,9 +177,10 @@ def import_reference():
     import deep_sort.sort.iou_matching as iou
     import deep_sort.sort.nn_matching as nn
     import deep_sort.sort.tracker as tracker
-    for m in (models, model_build, parse_config, img_detect, ds, reid_model, fe, kf, la, iou, nn, tracker):
+    for m in (models, model_build, parse_config, img_detect, video_detect, ds, reid_model, fe, kf, la, iou, nn, tracker):
         assert m.__file__.startswith(REF_ROOT), m.__file__
     ns.models, ns.model_build, ns.parse_config, ns.img_detect = models, model_build, parse_config, img_detect
+    ns.video_detect = video_detect
     ns.deep_sort, ns.reid_model, ns.feature_extractor = ds, reid_model, fe
     ns.kalman_filter, ns.linear_assignment, ns.iou_matching, ns.nn_matching, ns.tracker = kf, la, iou, nn, tracker
     return ns

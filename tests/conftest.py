@@ -54,3 +54,22 @@ def option_trace(name):
             return np.concatenate([ids, ids]), np.concatenate([tlwh, dup], 0), np.concatenate([f, f], 0)
         return g, dict(TRACE_PARAMS, nms_max_overlap=0.6), frame
     raise KeyError(name)
+
+
+def check_int_rows(out, ref, st, stats):
+    """int32 output rows (deep_sort.py:85-87 truncates fp32 boxes) against the reference's: ids / classes exact; a box column
+    may differ by one ONLY where the pre-truncation float (from the tracker state `st` right after that frame) sits within
+    2e-3 of an integer - the consequence of fp32 values that agree with the reference's to 1e-3."""
+    assert out.shape == ref.shape
+    assert np.array_equal(out[:, 4:], ref[:, 4:])
+    shown = (st["state"] == 2) & (st["tsu"] <= 1)
+    m = st["mean"][shown].astype(np.float64)
+    assert m.shape[0] == out.shape[0]
+    w, h = m[:, 2] * m[:, 3], m[:, 3]
+    x1, y1 = m[:, 0] - w / 2, m[:, 1] - h / 2
+    fl = np.stack([np.maximum(x1, 0), np.maximum(y1, 0), x1 + w, y1 + h], 1)
+    bad = out[:, :4] != ref[:, :4]
+    assert np.abs(out[:, :4] - ref[:, :4]).max(initial=0) <= 1
+    assert (np.abs(fl[bad] - np.rint(fl[bad])) < 2e-3).all(), fl[bad]
+    stats[0] += int(bad.sum())
+    stats[1] += bad.size

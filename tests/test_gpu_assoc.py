@@ -456,21 +456,7 @@ def test_lsap_bit_exact_vs_scipy_and_oracle():
 TRACE_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
 
 
-def _check_int_rows(out, ref, st, stats):
-    """int32 output rows (deep_sort.py:85-87 truncates fp32 boxes): ids/classes exact; a box column may differ by one ONLY
-    where the pre-truncation float sits within 2e-3 of an integer (fp32 values within 1e-3 of the reference's)."""
-    assert np.array_equal(out[:, 4:], ref[:, 4:])
-    shown = (st["state"] == 2) & (st["tsu"] <= 1)
-    m = st["mean"][shown].astype(np.float64)
-    assert m.shape[0] == out.shape[0]
-    w, h = m[:, 2] * m[:, 3], m[:, 3]
-    x1, y1 = m[:, 0] - w / 2, m[:, 1] - h / 2
-    fl = np.stack([np.maximum(x1, 0), np.maximum(y1, 0), x1 + w, y1 + h], 1)
-    bad = out[:, :4] != ref[:, :4]
-    assert np.abs(out[:, :4] - ref[:, :4]).max(initial=0) <= 1
-    assert (np.abs(fl[bad] - np.rint(fl[bad])) < 2e-3).all(), fl[bad]
-    stats[0] += int(bad.sum())
-    stats[1] += bad.size
+from conftest import check_int_rows as _check_int_rows  # noqa: E402
 
 
 def _run_trace(scene, g, params, drop=(), empty=(), frame_of=None):

@@ -62,6 +62,7 @@ def test_two_ranks_use_two_gpus():
                           "--no-roofline"], capture_output=True, text=True, timeout=1200)
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and len(set(line["config"]["rank_pci_bus_ids"])) == 2, line
+    assert line["config"]["transport"] == "rccl" and line["config"]["rccl_world"] == 2 and line["config"]["rccl_version"] > 0, line["config"]
 
 
 def _bench(tmp, extra, env=None, launcher=None):
@@ -86,6 +87,10 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["streams"] == 2 and line["scaling"] == "weak"
     assert line["config"]["rank_devices"] == [0, 0] and line["value"] > 0
     assert "one per GPU" in line["config"]["workload"] and "gloo" in line["exchange"]
+    # the run certifies its own transport: machine-readable, not inside a free-text string
+    c = line["config"]
+    assert c["transport"] == "gloo" and c["requested"] == "gloo" and c["rccl_world"] == 0 and c["rccl_version"] is None
+    assert len(c["rank_values"]) == 2 and all(v > 0 for v in c["rank_values"]) and c["exchange_block_rows"] >= 64
     g = np.load(both)
     total = 0
     for seed in (0, 1):
@@ -100,16 +105,48 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
     assert total == line["config"]["tracker_rows_out"] and total > 0                            # rank 0 holds BOTH streams' rows
 
 
-def test_rccl_refusal_falls_back_to_the_host_group(tmp_path):
-    """Two ranks on ONE device with the RCCL backend asked for: rank 0 creates the id, both ranks call ncclCommInitRank, RCCL
-    refuses (duplicate GPU) - every rank must then agree on the gloo transport and the run must complete (a scaling run must
-    not die because the collective library could not come up)."""
+def test_rccl_failure_fails_the_multi_gpu_bench(tmp_path):
+    """Two ranks on ONE device with the RCCL backend asked for (the default): both ranks pass the local preflight, rank 0 creates the
+    id, both call ncclCommInitRank, RCCL refuses (duplicate GPU).  Every rank agrees on the outcome over the host group (no rank is
+    left inside the collective) - and bench.py must then REFUSE to measure: a scaling run must not go green on gloo by accident."""
     env = dict(os.environ, YDS_DEVICE="0")
     env.pop("YDS_DIST_BACKEND", None)
-    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29583"]
-    line = _bench(tmp_path, ["--gpus", "2", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--batch", "4"], env, launcher)
-    assert line["n_gpus"] == 2 and line["exchange"].startswith("all-gather") and "RCCL unavailable" in line["exchange"]
-    assert line["config"]["tracker_rows_out"] > 0
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29583",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg4", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--cpu-frames", "0", "--no-extras", "--no-roofline", "--latency-steps", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode != 0, out.stdout[-500:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "error" in lines[0] and "RCCL" in lines[0]["error"] and "value" not in lines[0], lines
+
+
+def test_rccl_refusal_leaves_every_rank_on_the_host_group(tmp_path):
+    """The library level of the same situation: Ranks.connect() on two ranks sharing one device ends with BOTH ranks on gloo (same
+    decision everywhere, reason recorded), and the exchange step still works there."""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from yolo_deepsort_amd import _lib
+from yolo_deepsort_amd.dist import Ranks
+r = Ranks("nccl")
+_lib.init()
+r.connect()
+d = r.describe()
+assert d["transport"] == "gloo" and d["requested"] == "nccl" and d["rccl_world"] == 0 and d["fallback_reason"], d
+rows = r.gather_rows([np.full((r.rank + 1, 6), r.rank, np.int32)])
+assert rows[0][0].shape == (1, 6) and rows[1][0].shape == (2, 6)
+if r.rank == 0:
+    print("OK", d["fallback_reason"][:80])
+r.shutdown()
+''' % ROOT
+    script = tmp_path / "fallback.py"
+    script.write_text(code)
+    env = dict(os.environ, YDS_DEVICE="0")
+    env.pop("YDS_DIST_BACKEND", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29585", str(script)], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-800:] + out.stderr[-2000:]
 
 
 def test_rccl_comm_world_of_one():
@@ -137,8 +174,10 @@ def test_rccl_comm_world_of_one():
         out6 = np.zeros((3, cap, 6), np.int32)
         out6[0, :2] = outs[0]
         counts = np.array([2, -1, 0], np.int32)
-        allb = np.zeros((1, 3, dist.BLOCK), np.int32)
-        _lib.check(lib.yds_comm_allgather_rows(comm, _lib.ptr(out6), cap, _lib.ptr(counts), 3, _lib.ptr(allb)))
+        allb = np.zeros((1, 3, dist.block_ints(64)), np.int32)
+        need = C.c_int(-1)
+        _lib.check(lib.yds_comm_allgather_rows(comm, _lib.ptr(out6), cap, _lib.ptr(counts), 3, 64, _lib.ptr(allb), C.byref(need)))
+        assert need.value == 2
         rows = dist.unpack_rows(allb[0])
         assert np.array_equal(rows[0], outs[0]) and rows[1] is None and rows[2].shape == (0, 6)
         v = (C.c_double * 2)(3.5, -1.0)
@@ -154,9 +193,19 @@ def test_rccl_comm_world_of_one():
         back2 = np.zeros_like(blk)
         _lib.check(lib.yds_memcpy_d2h(_lib.ptr(back2), dst.ptr, blk.nbytes))
         assert np.array_equal(back2, blk)
-        too_many = np.zeros((1, cap, 6), np.int32)
-        assert lib.yds_comm_allgather_rows(comm, _lib.ptr(too_many), cap, _lib.ptr(np.array([257], np.int32)), 1, _lib.ptr(allb)) != 0
-        assert "exceed" in _lib.last_error()
+        # a frame that does not fit announces its size instead of failing; the caller repeats with a grown block
+        many = np.arange(cap * 6, dtype=np.int32).reshape(1, cap, 6)
+        small = np.zeros((1, 1, dist.block_ints(64)), np.int32)
+        _lib.check(lib.yds_comm_allgather_rows(comm, _lib.ptr(many), cap, _lib.ptr(np.array([257], np.int32)), 1, 64, _lib.ptr(small), C.byref(need)))
+        assert need.value == 257 and small[0, 0, 0] == -259
+        R = dist.rows_for(need.value)
+        grown = np.zeros((1, 1, dist.block_ints(R)), np.int32)
+        _lib.check(lib.yds_comm_allgather_rows(comm, _lib.ptr(many), cap, _lib.ptr(np.array([257], np.int32)), 1, R, _lib.ptr(grown), C.byref(need)))
+        assert np.array_equal(dist.unpack_rows(grown[0])[0], many[0, :257])
+        assert lib.yds_comm_allgather_rows(comm, _lib.ptr(many), cap, _lib.ptr(np.array([cap + 1], np.int32)), 1, R, _lib.ptr(grown), C.byref(need)) != 0
+        assert "holds" in _lib.last_error()
+        assert lib.yds_comm_preflight() == 0
+        assert lib.yds_comm_barrier(None) != 0 and "null" in _lib.last_error()
     finally:
         lib.yds_comm_destroy(comm)
 

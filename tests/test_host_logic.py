@@ -176,6 +176,13 @@ mine = [np.full((r.rank + 1, 6), 10 * r.rank + 1, np.int32), None if r.rank else
 streams = r.connect().gather_rows(mine)          # the exchange step: every rank ends up with both streams' rows
 assert len(streams) == 2 and streams[0][0].shape == (1, 6) and streams[1][0].shape == (2, 6)
 assert int(streams[1][0][0, 0]) == 11 and streams[0][1].shape == (0, 6) and streams[1][1] is None
+assert r.rows == 64 and r.transport == "gloo"
+# a frame with more rows than the block holds (only on rank 1): every rank grows its block alike and the exchange is repeated
+crowd = [np.arange(300 * 6, dtype=np.int32).reshape(300, 6) if r.rank else np.zeros((2, 6), np.int32)]
+streams = r.gather_rows(crowd)
+assert r.rows == 320 and np.array_equal(streams[1][0], np.arange(300 * 6, dtype=np.int32).reshape(300, 6)) and streams[0][0].shape == (2, 6)
+streams = r.gather_rows(mine)                     # the block stays grown, small frames still round-trip
+assert r.rows == 320 and streams[1][0].shape == (2, 6) and streams[1][1] is None
 if r.rank == 0:
     other = synth.PersonScene(5, seed=1).boxes(0)[1]
     assert dt == 2.0 and frames == 160
@@ -438,16 +445,17 @@ frames = list(range(7))                                       # 7 frames on 2 ra
 def detect(f):
     if f == 3:
         return None                                           # detector returned None: the tracker must not be called
-    d = f %% 4                                                # 0 detections at f = 4: the tracker IS called with D = 0
+    d = 70 if f == 5 else f %% 4                              # 0 detections at f = 4: the tracker IS called with D = 0; 70 at f = 5: the block (64) grows
     rng = np.random.RandomState(f)
     return rng.rand(d, 4).astype(np.float32), np.full(d, f, np.float32), rng.rand(d, 512).astype(np.float32)
 seen = []
 def track(tlwh, payload, feats):
     seen.append((tlwh.shape, payload.tolist(), float(feats.sum())))
     return ("rows", len(tlwh))
-out = ss.SingleStream(r, detect, track).run(frames)
+S = ss.SingleStream(r, detect, track)
+out = S.run(frames)
 if r.rank == 0:
-    assert len(out) == 7 and out[3] is None and out[4] == ("rows", 0) and out[6] == ("rows", 2)
+    assert len(out) == 7 and out[3] is None and out[4] == ("rows", 0) and out[5] == ("rows", 70) and out[6] == ("rows", 2)
     want = [detect(f) for f in frames if f != 3]
     assert len(seen) == 6
     for (shape, pay, fs), w in zip(seen, want):               # in frame order, bit-identical content
@@ -455,6 +463,7 @@ if r.rank == 0:
     print("OK")
 else:
     assert out == [] and seen == []
+assert S.cap == 128                                             # grown alike on both ranks
 r.shutdown()
 ''' % ROOT
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
@@ -467,5 +476,147 @@ r.shutdown()
         os.unlink(f.name)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-1000:] + out.stderr[-2000:]
     from yolo_deepsort_amd import single_stream as ss
+    small = ss.pack_frame(np.zeros((151, 4), np.float32), np.zeros(151), np.zeros((151, 512)))    # does not fit 64: announces its size
+    assert small[0] == -153 and ss.dets_needed(small[None]) == 151 and ss.cap_for(151) == 192
     with pytest.raises(ValueError):
-        ss.pack_frame(np.zeros((151, 4), np.float32), np.zeros(151), np.zeros((151, 512)))
+        ss.unpack_frame(small)
+    t, pl_, f = ss.unpack_frame(ss.pack_frame(np.ones((151, 4), np.float32), np.arange(151), np.ones((151, 512)), cap=192))
+    assert t.shape == (151, 4) and pl_[150] == 150 and f.shape == (151, 512)
+
+
+class _Clip:
+    """cv2.VideoCapture protocol over an in-memory BGR clip."""
+
+    def __init__(self, frames_bgr, fps):
+        self.frames, self.fps, self.pos, self.sets = frames_bgr, fps, 0, []
+
+    def isOpened(self):
+        return True
+
+    def get(self, prop):
+        n, h, w = self.frames.shape[:3]
+        return {5: self.fps, 6: 0.0, 3: float(w), 4: float(h), 7: float(n), 1: float(self.pos)}[prop]
+
+    def set(self, prop, value):
+        self.sets.append((prop, value))
+        self.pos = int(value)
+
+    def read(self):
+        if self.pos >= len(self.frames):
+            return False, None
+        self.pos += 1
+        return True, np.array(self.frames[self.pos - 1])
+
+
+def test_seek_and_writer_rate_truncate_like_the_reference():
+    """video_detect.py:92,97,101: video_fps = int(CAP_PROP_FPS); skip_frames = int(skip_secs) * video_fps; no seek past the end."""
+    from yolo_deepsort_amd.detect import FileVideoStream
+    clip = _Clip(np.zeros((400, 4, 4, 3), np.uint8), 29.97)
+    fvs = FileVideoStream(clip)
+    assert fvs.fps() == 29
+    fvs.seek_secs(10.9)
+    assert clip.sets == [(1, 290)]                            # not int(10.9 * 29.97) = 326
+    clip2 = _Clip(np.zeros((5, 4, 4, 3), np.uint8), 25.0)
+    FileVideoStream(clip2).seek_secs(6)                       # skip_secs > total_frames: "Can't skip over total video!", no seek
+    assert clip2.sets == []
+    clip3 = _Clip(np.zeros((5, 4, 4, 3), np.uint8), 25.0)
+    FileVideoStream(clip3).seek_secs(0)
+    assert clip3.sets == [(1, 0)]                             # the reference always issues the set (video_detect.py:101)
+
+
+@pytest.mark.parametrize("batch_frames", [1, 16])
+@pytest.mark.parametrize("case", ["tracker_skip2_mask", "tracker_every_frame", "no_tracker_skip3", "tracker_skip_secs"])
+def test_video_generator_control_flow_vs_reference_fixture(case, batch_frames, tmp_path):
+    """a9 on the CPU: the generator's control flow (skip gate, detector-None frames, hold, when the action module runs and what is
+    yielded when it does not, the skip_secs seek) against what the reference's own VideoDetector.detect yielded
+    (tests/golden/video_detect.npz), with stand-in stages that replay the fixture's per-frame results.  The device stages
+    themselves are compared in tests/test_gpu_video_detect.py."""
+    import json
+    from conftest import golden
+    from oracle.gen_golden import VIDEO_CASES, VIDEO_SCENE, CountingActions, video_clip
+    from yolo_deepsort_amd import detect as D
+    g = golden("video_detect")
+    c, sc = VIDEO_CASES[case], VIDEO_SCENE
+    frames, boxes, _ = video_clip(case)
+    key = lambda f: hash(np.ascontiguousarray(f).tobytes())
+    index = {key(f): t for t, f in enumerate(frames)}
+    served = [int(t) for t in g[f"{case}_served"]]
+    n = int(g[f"{case}_n"])
+    hold_of = {served[i]: (None if bool(g[f"{case}_f{i}_none"]) else g[f"{case}_f{i}_hold"]) for i in range(n)}
+
+    class Model:
+        img_size, batch_max = (sc["img"], sc["img"]), 16
+
+        def eval(self):
+            return self
+
+        def parameters(self):
+            yield type("P", (), {"device": "cpu"})()
+
+    class Tracker:
+        nms_max_overlap = 1.0
+
+        def update(self, boxs, conf, frame, cls):
+            return [r for r in hold_of[index[key(frame)]]]
+
+    names = tmp_path / "coco.names"
+    names.write_text(cfgs.coco_names_text())
+    act = CountingActions() if c["action"] else None
+    if batch_frames > 1 and not c["tracker"]:
+        pytest.skip("the batched pipeline needs a tracker (tracker=None keeps the frame-by-frame path)")
+    vd = D.VideoDetector(Model(), str(names), thres=sc["thres"], nms_thres=sc["nms_thres"], skip_frames=c["skip_frames"],
+                         class_mask=c["class_mask"], tracker=Tracker() if c["tracker"] else None, action_id=act, batch_frames=batch_frames)
+
+    def detect(frame):                                        # stand-in detector: None exactly where the scripted frame is empty
+        t = index[key(frame)]
+        if len(boxes[t]) == 0:
+            return None
+        return np.zeros((1, 6), np.float32) if c["tracker"] else hold_of[t]
+    vd.image_detector.detect = detect
+    if batch_frames > 1:
+        class Pipe:                                           # stand-in for pipeline.Pipeline.step: the fixture's rows per processed frame
+            def __init__(self):
+                self.groups = []
+
+            def step(self, buf, h, w, nfr, ahead=None, select_next=None):
+                return [None if hold_of[t] is None else np.asarray(hold_of[t], np.int32).reshape(-1, 6) for t in self.groups.pop(0)]
+        pipe = Pipe()
+        vd._pipe = pipe
+        orig = vd._processed_batches
+
+        def spy(*a, **k):
+            for grp in orig(*a, **k):
+                pipe.groups.append([index[key(f)] for f, proc in grp if proc])
+                yield grp
+        vd._processed_batches = spy
+
+        class Buf:
+            def __init__(self, arr):
+                self.arr = arr
+
+            @classmethod
+            def from_array(cls, arr):
+                return cls(arr)
+
+            def offset(self, o):
+                return self
+
+            def free(self):
+                pass
+        import yolo_deepsort_amd._lib as L
+        real = L.DeviceBuffer
+        L.DeviceBuffer = Buf
+    try:
+        clip = _Clip(frames[..., ::-1], sc["fps"])
+        got = list(vd.detect(clip, skip_secs=c["skip_secs"], show_fps=False))
+    finally:
+        if batch_frames > 1:
+            L.DeviceBuffer = real
+    assert len(got) == n
+    assert clip.sets == [(1, served[0])]
+    for i, (result, hold, actions) in enumerate(got):
+        ref = hold_of[served[i]]
+        assert (hold is None) == (ref is None), (case, i)
+        if ref is not None:
+            assert np.array_equal(np.asarray(hold).reshape(-1, 6), np.asarray(ref).reshape(-1, 6)), (case, i)
+        assert json.loads(json.dumps(actions)) == json.loads(str(g[f"{case}_f{i}_actions"])), (case, i, actions, str(g[f"{case}_f{i}_actions"]))

@@ -76,17 +76,24 @@ def test_default_device_under_per_rank_visibility_masks(monkeypatch):
 
 
 def test_exchange_block_round_trip():
-    """dist.pack_rows / unpack_rows: {count, rows[256][6]} per frame, -1 = the detector returned None."""
+    """dist.pack_rows / unpack_rows: {header, rows[R][6]} per frame; -1 = the detector returned None, -(2 + n) = n rows did not
+    fit and the block has to grow (it does, in steps of 64 rows)."""
     import numpy as np
     import pytest
     from yolo_deepsort_amd import dist
     outs = [np.arange(18, dtype=np.int32).reshape(3, 6), None, np.zeros((0, 6), np.int32), []]
     blk = dist.pack_rows(outs)
-    assert blk.shape == (4, 1 + 256 * 6) and blk[:, 0].tolist() == [3, -1, 0, 0]
+    assert blk.shape == (4, 1 + 64 * 6) and blk[:, 0].tolist() == [3, -1, 0, 0]
     back = dist.unpack_rows(blk)
     assert np.array_equal(back[0], outs[0]) and back[1] is None and back[2].shape == (0, 6) and back[3].shape == (0, 6)
+    big = [np.arange(257 * 6, dtype=np.int32).reshape(257, 6), None]
+    small = dist.pack_rows(big, 64)
+    assert small[:, 0].tolist() == [-259, -1] and dist.rows_needed(small) == 257
     with pytest.raises(ValueError):
-        dist.pack_rows([np.zeros((257, 6), np.int32)])
+        dist.unpack_rows(small)
+    assert dist.rows_for(257) == 320 and dist.rows_for(0) == 64 and dist.rows_for(64) == 64
+    grown = dist.pack_rows(big, dist.rows_for(257))
+    assert grown.shape == (2, 1 + 320 * 6) and np.array_equal(dist.unpack_rows(grown)[0], big[0])
 
 
 def test_constructors_do_not_name_a_device():

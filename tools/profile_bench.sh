@@ -1,22 +1,28 @@
-# rocprofv3 kernel statistics of the default bench command (run on the GPU box): tools/profile_bench.sh <cfg> <outdir>
-# pass 1 fills the conv tune cache so that the profiled pass holds no autotune launches
+# rocprofv3 kernel statistics of the default bench command (run on the GPU box): [MATH=f32] [PMC=1] tools/profile_bench.sh <cfg> <outdir>
+# pass 1 fills the conv tune cache so that the profiled pass holds no autotune launches.  MATH=f32 profiles the exact-fp32 leg
+# (bench.py --math f32: the arithmetic of value_f32_math / roofline_f32); output names then carry the suffix _f32.
 export TMPDIR=/tmp
 R=$PWD; cfg=${1:-cfg2}; out=$R/${2:-gpurun_out/prof}; mkdir -p $out
-export YDS_TUNE_CACHE=/tmp/yds_tune_$cfg.txt
-python bench.py --config $cfg --steps 5 --warmup 2 --no-extras --cpu-frames 0 --latency-steps 0 > $out/bench_${cfg}_plain.json 2>$out/err1.log
+math=${MATH:-f16x3}; sfx=""; [ "$math" = "f32" ] && sfx="_f32"
+steps=${STEPS:-20}; [ "$math" = "f32" ] && steps=${STEPS:-8}
+export YDS_TUNE_CACHE=/tmp/yds_tune_$cfg$sfx.txt
+common="--config $cfg --math $math --no-extras --cpu-frames 0 --latency-steps 0"
+python bench.py $common --steps 5 --warmup 2 > $out/bench_${cfg}${sfx}_plain.json 2>$out/err1.log
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench_$cfg -- python $R/bench.py --config $cfg --steps 20 --warmup 3 --no-extras --cpu-frames 0 --latency-steps 0 > $out/bench_${cfg}_under_rocprof.json 2>$out/err2.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench_$cfg$sfx -- python $R/bench.py $common --steps $steps --warmup 3 > $out/bench_${cfg}${sfx}_under_rocprof.json 2>$out/err2.log
 cd $R
+python tools/rocprof_agg.py $out/bench_${cfg}${sfx}_kernel_stats.csv > $out/${cfg}${sfx}_conv_by_tile.txt
+python tools/rocprof_by_grid.py $out/bench_${cfg}${sfx}_kernel_trace.csv > $out/${cfg}${sfx}_conv_by_grid.txt
 ls $out
 # HBM traffic of the conv kernels: PMC passes of their own (kernel trace only), FETCH_SIZE and WRITE_SIZE separately
 if [ "${PMC:-0}" = "1" ]; then
   cd /tmp
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o pmc_${cfg}_$c -- python $R/bench.py --config $cfg --steps 3 --warmup 1 --no-extras --cpu-frames 0 --no-roofline --latency-steps 0 > /dev/null 2>$out/err_pmc_$c.log
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o pmc_${cfg}${sfx}_$c -- python $R/bench.py $common --steps 3 --warmup 1 --no-roofline > /dev/null 2>$out/err_pmc_$c.log
   done
   cd $R
-  python tools/traffic_from_pmc.py $out/pmc_${cfg}_FETCH_SIZE_counter_collection.csv $out/pmc_${cfg}_WRITE_SIZE_counter_collection.csv > $out/traffic_$cfg.json
-  cat $out/traffic_$cfg.json
+  python tools/traffic_from_pmc.py $out/pmc_${cfg}${sfx}_FETCH_SIZE_counter_collection.csv $out/pmc_${cfg}${sfx}_WRITE_SIZE_counter_collection.csv > $out/traffic_$cfg$sfx.json
+  cat $out/traffic_$cfg$sfx.json
 fi
 # the per-dispatch traces are tens of MB: keep the summaries only (gpurun copies at most 64 MiB back)
-rm -f $out/*_kernel_trace.csv $out/pmc_${cfg}_*_counter_collection.csv $out/*_agent_info.csv
+rm -f $out/*_kernel_trace.csv $out/pmc_${cfg}${sfx}_*_counter_collection.csv $out/*_agent_info.csv

@@ -104,10 +104,12 @@ SIGNATURES = {
     "yds_comm_rccl_version": (_I, []),
     "yds_comm_allgather": (_I, [_P, _P, _SZ, _P]),
     "yds_comm_allgather_dev": (_I, [_P, _P, _SZ, _P]),
-    "yds_comm_allgather_rows": (_I, [_P, _P, _I, _P, _I, _P]),
+    "yds_comm_allgather_rows": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "yds_comm_preflight": (_I, []),
     "yds_comm_allreduce_f64": (_I, [_P, _P, _I, _I]),
     "yds_comm_barrier": (_I, [_P]),
     "yds_tracker_get_payload": (_I, [_P, _P, _I]),
+    "yds_tracker_get_age": (_I, [_P, _P, _I]),
     "yds_tracker_gallery_rows": (_I, [_P]),
     "yds_kalman_gating_ex": (_I, [_P, _P, _I, _P, _I, _I, _P]),
     "yds_kalman_initiate": (_I, [_P, _I, _P, _P]),

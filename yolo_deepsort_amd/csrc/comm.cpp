@@ -1,6 +1,6 @@
 // Multi-GPU exchange step of the stream-sharded run: one process per GPU, one video stream per rank, and ONE
-// collective per frame batch - an all-gather of every rank's fixed-size result block {int32 count; int32 rows[256][6]} per
-// frame so that rank 0 can emit all streams' tracker rows - plus small all-reduces (counters, the max-over-ranks time)
+// collective per frame batch - an all-gather of every rank's result block {int32 count; int32 rows[R][6]} per frame (R chosen by
+// the caller, grown when a frame has more rows) so that rank 0 can emit all streams' tracker rows - plus small all-reduces (counters, the max-over-ranks time)
 // and a barrier.  RCCL directly (ncclCommInitRank from an id the launcher distributes), on this library's own stream on
 // the bound device; no torch types, no torch.distributed on the data path.
 //
@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <algorithm>
 #include <memory>
 #include <string>
 #include <vector>
@@ -105,7 +106,28 @@ struct yds_comm {
     }
 };
 
+namespace {
+yds_comm *live(yds_comm *c) {
+    if (!c || !c->comm) yds::fail("comm: null or destroyed communicator handle");
+    return c;
+}
+}  // namespace
+
 extern "C" {
+
+/* local, NON-collective check that a communicator can be attempted: librccl found next to this runtime, its symbols resolved, a
+ * device bound by yds_init, a stream created on it.  The ranks vote on it over their host group BEFORE any of them enters
+ * ncclCommInitRank (a collective: a rank that fails earlier would leave the others blocked in it). */
+int yds_comm_preflight(void) {
+    YDS_API_BEGIN
+    if (yds::bound_device() < 0) yds::fail("comm: yds_init has not bound a device");
+    int v = 0;
+    YDS_NCCL(yds::rccl().GetVersion(&v));
+    hipStream_t s = yds::make_stream(true);
+    YDS_HIP(hipStreamSynchronize(s));
+    YDS_HIP(hipStreamDestroy(s));
+    YDS_API_END
+}
 
 int yds_comm_unique_id(void *id128_out) {
     YDS_API_BEGIN
@@ -160,6 +182,7 @@ int yds_comm_rccl_version(void) {
 
 int yds_comm_allgather_dev(yds_comm *c, const void *send_dev, size_t bytes, void *recv_dev) {
     YDS_API_BEGIN
+    live(c);
     YDS_NCCL(yds::rccl().AllGather(send_dev, recv_dev, bytes, ncclChar, c->comm, c->stream));
     YDS_HIP(hipStreamSynchronize(c->stream));
     YDS_API_END
@@ -167,6 +190,7 @@ int yds_comm_allgather_dev(yds_comm *c, const void *send_dev, size_t bytes, void
 
 int yds_comm_allgather(yds_comm *c, const void *send_host, size_t bytes, void *recv_host) {
     YDS_API_BEGIN
+    live(c);
     const size_t total = bytes * (size_t)c->world;
     c->ensure(bytes, total);
     memcpy(c->pin, send_host, bytes);
@@ -178,24 +202,38 @@ int yds_comm_allgather(yds_comm *c, const void *send_host, size_t bytes, void *r
     YDS_API_END
 }
 
-/* the result block of the exchange step: per frame {int32 count; int32 rows[YDS_COMM_MAX_ROWS][6]} */
-int yds_comm_allgather_rows(yds_comm *c, const int32_t *out6_host, int cap, const int32_t *counts_host, int batch, int32_t *all_host) {
+/* the result block of the exchange step: per frame {int32 header; int32 rows[rows_per_block][6]}; header = row count, -1 = the
+ * detector returned None, -(2 + n) = the frame has n > rows_per_block rows and was not sent.  *rows_needed = the largest row count
+ * any rank announced: when it exceeds rows_per_block the caller repeats the call with a block of at least that many rows (every
+ * rank sees the same headers, so every rank takes the same decision). */
+int yds_comm_allgather_rows(yds_comm *c, const int32_t *out6_host, int cap, const int32_t *counts_host, int batch, int rows_per_block,
+                            int32_t *all_host, int *rows_needed) {
     YDS_API_BEGIN
-    constexpr int BLK = 1 + YDS_COMM_MAX_ROWS * 6;
+    live(c);
+    if (rows_per_block < 1) yds::fail("comm: rows_per_block must be positive");
+    const int BLK = 1 + rows_per_block * 6;
     std::vector<int32_t> blk((size_t)batch * BLK, 0);
     for (int b = 0; b < batch; ++b) {
         const int n = counts_host[b];
-        if (n > YDS_COMM_MAX_ROWS) yds::fail("comm: %d tracker rows in one frame exceed the exchange block (%d)", n, YDS_COMM_MAX_ROWS);
-        blk[(size_t)b * BLK] = n;                                        // -1 = the detector returned None for this frame
-        if (n > 0) memcpy(&blk[(size_t)b * BLK + 1], out6_host + (size_t)b * cap * 6, (size_t)n * 6 * sizeof(int32_t));
+        if (n > cap) yds::fail("comm: frame %d announces %d rows, the caller's buffer holds %d", b, n, cap);
+        blk[(size_t)b * BLK] = n > rows_per_block ? -(2 + n) : n;
+        if (n > 0 && n <= rows_per_block) memcpy(&blk[(size_t)b * BLK + 1], out6_host + (size_t)b * cap * 6, (size_t)n * 6 * sizeof(int32_t));
     }
-    return yds_comm_allgather(c, blk.data(), blk.size() * sizeof(int32_t), all_host);
+    if (yds_comm_allgather(c, blk.data(), blk.size() * sizeof(int32_t), all_host) != 0) return -1;
+    int need = 0;
+    for (size_t f = 0; f < (size_t)c->world * batch; ++f) {
+        const int h = all_host[f * BLK];
+        need = std::max(need, h <= -2 ? -2 - h : std::max(h, 0));
+    }
+    if (rows_needed) *rows_needed = need;
+    return 0;
     }
     catch (const std::exception &e) { yds::set_error(e.what()); return -1; }
 }
 
 int yds_comm_allreduce_f64(yds_comm *c, double *vals_host, int n, int op) {
     YDS_API_BEGIN
+    live(c);
     if (op != 0 && op != 1) yds::fail("comm: op must be 0 (sum) or 1 (max)");
     const size_t bytes = (size_t)n * sizeof(double);
     c->ensure(bytes, bytes);

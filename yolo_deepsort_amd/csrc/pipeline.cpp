@@ -29,22 +29,27 @@ public:
             for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
             nms[k].reset(new NmsWorkspace(4096, net->batch_max));
         }
-        for (int k = 0; k < NSTAGE; ++k) YDS_HIP(hipEventCreateWithFlags(&up_done[k], hipEventDisableTiming));
+        for (int k = 0; k < NSTAGE; ++k)
+            for (hipEvent_t *e : {&up_done[k], &rd_det[k], &rd_reid[k]}) YDS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         YDS_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     }
     ~Pipeline() {
         for (int k = 0; k < 2; ++k) {
             for (hipEvent_t e : {e0[k], e1[k], e2[k], e_nms[k]}) (void)hipEventDestroy(e);
         }
-        for (int k = 0; k < NSTAGE; ++k) (void)hipEventDestroy(up_done[k]);
+        for (int k = 0; k < NSTAGE; ++k)
+            for (hipEvent_t e : {up_done[k], rd_det[k], rd_reid[k]}) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(copy_stream);
     }
 
     // ---- frames handed over as HOST memory (img_detect.py:70-71 starts from a host frame) ------------------------------
     // Three device staging buffers take turns; the copy runs on its own stream (SDMA engine), so uploads overlap the detector /
-    // ReID / association of earlier batches.  A batch is matched by its host pointer ONCE (the slot is forgotten when the step
-    // that consumed it returns), so a caller may reuse a host buffer for new frames.  Pinned source memory (yds_host_alloc)
-    // makes the copy asynchronous and full speed.
+    // ReID / association of earlier batches.  A batch is matched by its host pointer for a BOUNDED time: the slot is forgotten
+    // when the step that consumed it returns, and an announced batch that is never consumed is forgotten too (`next` must be the
+    // following call's `frames`, a prefetch_host batch must be consumed within two calls: stage_ttl) - so a caller may reuse a
+    // host buffer for new frames and a later buffer at the same address can never match stale device frames.  A slot is only
+    // overwritten after the kernels that read it (the detector's resize, the extractor's crops) have passed: the copy stream
+    // waits on their events.  Pinned source memory (yds_host_alloc) makes the copy asynchronous and full speed.
     // Depth: step_host(frames, next) starts the upload of `next` when it is called - but the detector stream runs a whole pass
     // ahead of the host chain (NMS -> ReID -> association), so it wants `next` at that very moment and would idle for the
     // 1.7 ms of a 100 MB copy (1352 vs 1447 frames/s).  prefetch_host(frames of the step after next) starts that copy one
@@ -54,7 +59,7 @@ public:
             if (host && stage_host[k] == host) return k;
         return -1;
     }
-    int upload(const uint8_t *host, size_t bytes, int keep_a = -1, int keep_b = -1) {
+    int upload(const uint8_t *host, size_t bytes, int ttl, int keep_a = -1, int keep_b = -1) {
         int k = -1;
         for (int pass = 0; pass < 2 && k < 0; ++pass)               // next slot in turn: an empty one first, else any not in use
             for (int t = 1; t <= NSTAGE; ++t) {
@@ -65,7 +70,15 @@ public:
             }
         if (k < 0) fail("pipeline: no staging buffer free");
         stage_turn = k;
+        // the previous tenant's readers (a prefetched detector pass, an early ReID pass) may still be running on their streams
+        if (rd_det_set[k]) { YDS_HIP(hipStreamWaitEvent(copy_stream, rd_det[k], 0)); rd_det_set[k] = false; }
+        if (rd_reid_set[k]) { YDS_HIP(hipStreamWaitEvent(copy_stream, rd_reid[k], 0)); rd_reid_set[k] = false; }
+        if (stage[k].n < bytes) {                                    // (re)allocation frees the old buffer: its readers must be done
+            YDS_HIP(hipStreamSynchronize(net->stream));
+            YDS_HIP(hipStreamSynchronize(reid->stream));
+        }
         stage[k].ensure(bytes);
+        stage_ttl[k] = ttl;
         YDS_HIP(hipMemcpyAsync(stage[k].p, host, bytes, hipMemcpyHostToDevice, copy_stream));
         YDS_HIP(hipEventRecord(up_done[k], copy_stream));
         stage_host[k] = host;
@@ -74,25 +87,32 @@ public:
     }
     void prefetch_host(const uint8_t *frames_host, int h, int w, int batch) {
         if (staged(frames_host) >= 0) return;
-        upload(frames_host, (size_t)batch * h * w * 3, cur_k, next_k);
+        upload(frames_host, (size_t)batch * h * w * 3, 3, cur_k, next_k);      // survives this call's step and the next: consumed by the one after
     }
     void step_host(const uint8_t *frames_host, const uint8_t *next_host, int next_inject_set, int h, int w, int batch, int32_t *out6, int cap,
                    int32_t *counts) {
         const size_t bytes = (size_t)batch * h * w * 3;
         // batches handed over earlier (as `next` of the previous call, or through prefetch_host) are already resident or on their way
         cur_k = staged(frames_host);
-        if (cur_k < 0) cur_k = upload(frames_host, bytes, staged(next_host));
+        if (cur_k < 0) cur_k = upload(frames_host, bytes, 1, staged(next_host));
         next_k = -1;
         if (next_host) {
             next_k = staged(next_host);
-            if (next_k < 0) next_k = upload(next_host, bytes, cur_k);
+            if (next_k < 0) next_k = upload(next_host, bytes, 2, cur_k);              // survives this step: the next call's `frames`
         }
         step(stage[cur_k].p, next_k >= 0 ? stage[next_k].p : nullptr, next_inject_set, h, w, batch, out6, cap, counts);
         // every host buffer handed over so far may be reused by the caller when this returns; the consumed batch is forgotten
         for (int k = 0; k < NSTAGE; ++k)
             if (up_pending[k]) { YDS_HIP(hipEventSynchronize(up_done[k])); up_pending[k] = false; }
         stage_host[cur_k] = nullptr;
+        for (int k = 0; k < NSTAGE; ++k)                            // announced but never consumed: forget it (its address may be reused)
+            if (k != cur_k && stage_host[k] && --stage_ttl[k] <= 0) stage_host[k] = nullptr;
         cur_k = -1;
+    }
+    int slot_of(const uint8_t *frames_dev) const {
+        for (int b = 0; b < NSTAGE; ++b)
+            if (stage[b].p && frames_dev == stage[b].p) return b;
+        return -1;
     }
 
     // One detector pass over a batch AND its NMS, all asynchronous on the detector stream.  Two NMS workspaces (and
@@ -106,6 +126,7 @@ public:
         YDS_HIP(hipEventRecord(e0[k], net->stream));
         launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream);
         YDS_HIP(hipEventRecord(e1[k], net->stream));
+        if (const int sl = slot_of(frames_dev); sl >= 0) { YDS_HIP(hipEventRecord(rd_det[sl], net->stream)); rd_det_set[sl] = true; }
         net->forward_resized(batch);
         YDS_HIP(hipEventRecord(e2[k], net->stream));
         const float sx = (float)((double)w / net->img_w), sy = (float)((double)h / net->img_h);
@@ -166,7 +187,10 @@ public:
     }
     // one ReID pass over the crops of the whole batch, asynchronous on the extractor's stream
     void launch_reid(Dets &d, int h, int w) {
-        if (!d.payload.empty()) reid->embed_multi_dev(d.frames, h, w, d.tlwh.data(), d.frame_of.data(), (int)d.payload.size());
+        if (!d.payload.empty()) {
+            reid->embed_multi_dev(d.frames, h, w, d.tlwh.data(), d.frame_of.data(), (int)d.payload.size());
+            if (const int sl = slot_of(d.frames); sl >= 0) { YDS_HIP(hipEventRecord(rd_reid[sl], reid->stream)); rd_reid_set[sl] = true; }
+        }
         d.reid_in_flight = true;
     }
 
@@ -236,6 +260,9 @@ public:
     DevBuf<uint8_t> stage[NSTAGE];            // device copies of host frames (step_host / prefetch_host)
     const uint8_t *stage_host[NSTAGE] = {nullptr, nullptr, nullptr};
     bool up_pending[NSTAGE] = {false, false, false};
+    int stage_ttl[NSTAGE] = {0, 0, 0};        // step_host calls an unconsumed slot may still survive
+    hipEvent_t rd_det[NSTAGE] = {}, rd_reid[NSTAGE] = {};     // recorded behind the last kernels that read a slot
+    bool rd_det_set[NSTAGE] = {false, false, false}, rd_reid_set[NSTAGE] = {false, false, false};
     int cur_k = -1, next_k = -1;
     hipEvent_t up_done[NSTAGE] = {};
     hipStream_t copy_stream = nullptr;

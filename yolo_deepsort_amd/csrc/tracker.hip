@@ -1570,6 +1570,14 @@ int yds_tracker_get_payload(yds_trk *t, float *payload, int cap) {
     if (n) YDS_HIP(hipMemcpy(payload, k->table.p + (size_t)8 * k->capacity, (size_t)n * 4, hipMemcpyDeviceToHost));
     YDS_API_END
 }
+int yds_tracker_get_age(yds_trk *t, int32_t *age, int cap) {
+    YDS_API_BEGIN
+    yds::Tracker *k = impl(t);
+    const int n = k->T_host;
+    if (n > cap) yds::fail("tracker: %d tracks exceed cap %d", n, cap);
+    if (n) YDS_HIP(hipMemcpy(age, k->table.p + (size_t)3 * k->capacity, (size_t)n * 4, hipMemcpyDeviceToHost));
+    YDS_API_END
+}
 int yds_tracker_last_unmatched(yds_trk *t, int32_t *um_tracks, int cap_t, int *n_t, int32_t *um_dets, int cap_d, int *n_d) {
     YDS_API_BEGIN
     const auto &a = impl(t)->last_um_t, &b = impl(t)->last_um_d;
@@ -1731,16 +1739,27 @@ static int nn_min_cost(const float *gallery_host, const int32_t *seg_offsets_hos
                        int euclid) {
     YDS_API_BEGIN
     using namespace yds;
-    if (dim != EMB) fail("cosine: feature dimension must be %d", EMB);
+    // nn_matching.py:4-53 is dimension agnostic; the kernel reduces 512-wide rows, so narrower embeddings are zero padded (zeros
+    // change neither a dot product nor a norm) and wider ones are refused
+    if (dim < 1 || dim > EMB) fail("nn distance: feature dimension %d outside [1, %d]", dim, EMB);
     if (T == 0 || D == 0) return 0;
     hipStream_t s = g_scratch.stream();
     int budget = 1;
-    for (int t = 0; t < T; ++t) budget = std::max(budget, seg_offsets_host[t + 1] - seg_offsets_host[t]);
-    std::vector<float> g((size_t)T * budget * EMB, 0.f);
+    for (int t = 0; t < T; ++t) {
+        if (seg_offsets_host[t + 1] < seg_offsets_host[t]) fail("nn distance: segment offsets must not decrease");
+        budget = std::max(budget, seg_offsets_host[t + 1] - seg_offsets_host[t]);
+    }
+    std::vector<float> g((size_t)T * budget * EMB, 0.f), fpad;
     std::vector<int> rows(T);
     for (int t = 0; t < T; ++t) {
         rows[t] = seg_offsets_host[t + 1] - seg_offsets_host[t];
-        memcpy(&g[(size_t)t * budget * EMB], gallery_host + (size_t)seg_offsets_host[t] * EMB, (size_t)rows[t] * EMB * 4);
+        for (int r = 0; r < rows[t]; ++r)
+            memcpy(&g[((size_t)t * budget + r) * EMB], gallery_host + ((size_t)seg_offsets_host[t] + r) * dim, (size_t)dim * 4);
+    }
+    if (dim != EMB) {
+        fpad.assign((size_t)D * EMB, 0.f);
+        for (int d = 0; d < D; ++d) memcpy(&fpad[(size_t)d * EMB], feats_host + (size_t)d * dim, (size_t)dim * 4);
+        feats_host = fpad.data();
     }
     DevBuf<float> gd, fd, gn(g.size()), fn((size_t)D * EMB), o((size_t)T * D); DevBuf<int> sl, nr;
     gd.upload(g.data(), g.size(), s); fd.upload(feats_host, (size_t)D * EMB, s);

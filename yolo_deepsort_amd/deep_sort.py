@@ -222,8 +222,9 @@ class DeepSort(object):
         d = tlwh.shape[0]
         if d == 0:
             return np.zeros(0, np.int32)
-        # (the reference sorts np.array([d.confidence ...]) of Python ints = int64: same dtype here, argsort's tie order is per dtype)
-        order = np.ascontiguousarray(np.argsort(np.ones(d, dtype=np.int64)), dtype=np.int32)
+        # (Detection.__init__ stores float(confidence), detection.py:29, so the reference sorts a float64 vector of ones: same
+        # dtype here - argsort's order among ties is numpy's, per dtype)
+        order = np.ascontiguousarray(np.argsort(np.ones(d, dtype=np.float64)), dtype=np.int32)
         pick = np.zeros(d, np.int32)
         n = C.c_int(0)
         _lib.check(_lib.load().yds_tracker_nms(_lib.ptr(tlwh), _lib.ptr(order), d, float(self.nms_max_overlap), _lib.ptr(pick), C.byref(n)))

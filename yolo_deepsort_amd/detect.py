@@ -75,8 +75,12 @@ class FileVideoStream:
     """Threaded frame reader with a bounded queue and a per-frame transform - the role of ``imutils.video.FileVideoStream``
     in the reference (yolo3/detect/video_detect.py:12,86,112-126: ``FileVideoStream(path, _transform).start()``, ``more()``,
     ``read()``).  Sources: a video file / camera index through cv2.VideoCapture when cv2 is installed, or an ``.npy`` file
-    holding uint8 [N,H,W,3] frames (what the tests and synthetic streams use).  Frames are BGR like cv2's; ``transform``
-    is applied on the reader thread (the reference passes BGR->RGB)."""
+    holding uint8 [N,H,W,3] frames (what the tests and synthetic streams use), or any object with cv2.VideoCapture's
+    ``isOpened / read / get / set / release`` (an already-open capture, an in-memory clip).  Frames are BGR like cv2's;
+    ``transform`` is applied on the reader thread (the reference passes BGR->RGB)."""
+
+    # cv2.CAP_PROP_* ordinals (stable across OpenCV 3.x / 4.x), so that capture-like sources work without cv2
+    CAP_PROP_POS_FRAMES, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT = 1, 5, 7
 
     def __init__(self, path, transform=None, queue_size=128):
         import queue
@@ -87,6 +91,10 @@ class FileVideoStream:
         self._cap = None
         if isinstance(path, str) and path.endswith(".npy"):
             self._frames = iter(np.load(path, mmap_mode="r"))
+        elif all(hasattr(path, a) for a in ("isOpened", "read", "get", "set")):
+            self._cap = path
+            if not self._cap.isOpened():
+                raise IOError("Couldn't open webcam or video")
         else:
             try:
                 import cv2
@@ -127,7 +135,7 @@ class FileVideoStream:
                         pass
         finally:
             self.stopped = True
-            if self._cap is not None:              # released on the thread that reads it (never concurrently with read())
+            if self._cap is not None and hasattr(self._cap, "release"):   # released on the thread that reads it (never concurrently with read())
                 self._cap.release()
             try:
                 self.Q.put_nowait(None)            # end marker wakes a blocked reader
@@ -147,25 +155,26 @@ class FileVideoStream:
                     return None
 
     def fps(self):
-        """CAP_PROP_FPS of a cv2 source (None for .npy / iterable sources)."""
+        """video_detect.py:92: int(CAP_PROP_FPS) of a capture - the reference truncates the rate before it uses it for the seek
+        and for the writer (29.97 -> 29).  None for .npy sources (no rate stored with them)."""
         if self._cap is None:
             return None
-        import cv2
-        v = self._cap.get(cv2.CAP_PROP_FPS)
-        return float(v) if v and v > 0 else None
+        v = self._cap.get(self.CAP_PROP_FPS)
+        return int(v) if v and v > 0 else None
 
     def seek_secs(self, skip_secs):
-        """video_detect.py:99-101: vid.set(CAP_PROP_POS_FRAMES, skip_secs * fps); before start().  .npy sources skip
-        skip_secs * 25 frames (no frame rate is stored with them)."""
-        if not skip_secs:
-            return
+        """video_detect.py:97-101: skip_frames = int(skip_secs) * int(fps); the seek is refused (with the reference's message)
+        when skip_secs exceeds the frame count; before start().  .npy sources count 25 frames per second."""
         if self._thread is not None:
             raise RuntimeError("seek_secs must be called before start()")
         if self._cap is not None:
-            import cv2
-            self._cap.set(cv2.CAP_PROP_POS_FRAMES, int(skip_secs * (self.fps() or 25.0)))
+            total = int(self._cap.get(self.CAP_PROP_FRAME_COUNT))
+            if skip_secs > total:
+                print("Can't skip over total video!")
+            else:
+                self._cap.set(self.CAP_PROP_POS_FRAMES, int(skip_secs) * (self.fps() or 0))
         else:
-            for _ in range(int(skip_secs * 25)):
+            for _ in range(int(skip_secs) * 25):
                 if next(self._frames, None) is None:
                     break
 
@@ -182,7 +191,7 @@ class FileVideoStream:
                 except queue.Empty:
                     pass
                 t.join(timeout=0.05)
-        elif t is None and self._cap is not None:
+        elif t is None and self._cap is not None and hasattr(self._cap, "release"):
             self._cap.release()
         try:
             while True:
@@ -220,7 +229,7 @@ class VideoDetector:
 
     def _frames(self, video_path, skip_secs=0):
         self._source_fps = None
-        if hasattr(video_path, "__iter__") and not isinstance(video_path, (str, bytes)):
+        if hasattr(video_path, "__iter__") and not isinstance(video_path, (str, bytes)) and not hasattr(video_path, "isOpened"):
             if skip_secs:
                 raise ValueError("skip_secs needs a seekable source (a video file or an .npy path), not an iterable of frames")
             for f in video_path:           # already-decoded RGB frames
@@ -240,9 +249,11 @@ class VideoDetector:
             fvs.stop()
 
     def process(self, frame):
-        """The hot glue of video_detect.py:134-157 for one frame: returns hold_detections."""
+        """The hot glue of video_detect.py:134-157 for one frame: returns hold_detections (self._tracked: the tracker branch
+        :137-154 ran, i.e. the detector returned rows and a tracker is set)."""
         detections = self.image_detector.detect(frame)
-        if detections is not None and self.tracker is not None:
+        self._tracked = detections is not None and self.tracker is not None
+        if self._tracked:
             det = detections.numpy() if hasattr(detections, "numpy") else detections
             boxs = p1p2Toxywh(det[:, :4])
             class_ids = det[:, -1]
@@ -303,7 +314,7 @@ class VideoDetector:
             if det.model.batch_max < self.batch_frames:
                 det.model.set_batch_max(self.batch_frames)
             self._pipe = pl.Pipeline(det.model, self.tracker, det.thres, det.nms_thres, class_mask=self.class_mask)
-        hold_detections = None
+        hold_detections, actions = None, []
 
         def upload(group):
             fr = [f for f, proc in group if proc]
@@ -322,13 +333,14 @@ class VideoDetector:
                 outs = self._pipe.step(buf.offset(0), h, w, n, ahead)
             k = 0
             for frame, proc in cur:
-                actions = []
                 if proc:
                     o = outs[k]
                     k += 1
                     hold_detections = None if o is None else (o if len(o) else [])
-                    if self.action_id is not None and hold_detections is not None:
-                        actions = self.action_id.update(hold_detections)
+                    if hold_detections is not None:        # video_detect.py:137-154; a detector-None frame leaves `actions` as it was
+                        actions = self.action_id.update(hold_detections) if self.action_id is not None else []
+                else:
+                    actions = []                           # :158-159
                 yield self._render(frame, hold_detections, show_fps), hold_detections, actions
             if cur_dev is not None:
                 cur_dev[0].free()
@@ -337,8 +349,8 @@ class VideoDetector:
     def detect(self, video_path, output_path=None, skip_secs=0, real_show=False, show_fps=True):
         """Generator of (bgr_image, hold_detections, actions) like video_detect.py:78-199.  output_path: every result is
         also written - through cv2.VideoWriter when cv2 is installed, as one uint8 [N,H,W,3] array for a path ending in
-        ``.npy``; real_show needs cv2 (ignored without it); skip_secs seeks a cv2 capture to skip_secs * fps frames (an .npy
-        source skips skip_secs * 25 frames; an iterable of frames cannot seek and raises)."""
+        ``.npy``; real_show needs cv2 (ignored without it); skip_secs seeks a capture to int(skip_secs) * int(fps) frames like
+        video_detect.py:92-101 (an .npy source skips int(skip_secs) * 25 frames; an iterable of frames cannot seek and raises)."""
         writer, frames_out, cv2 = None, None, None
         try:
             import cv2 as _cv2
@@ -357,7 +369,7 @@ class VideoDetector:
                 elif output_path is not None:
                     if writer is None:
                         fourcc = cv2.VideoWriter_fourcc(*self.fourcc) if isinstance(self.fourcc, str) else self.fourcc
-                        # video_detect.py:91-96: the writer takes the SOURCE frame rate; 25 only where the source has none (.npy, iterables)
+                        # video_detect.py:92,106: the writer takes int(SOURCE frame rate); 25 only where the source has none (.npy, iterables)
                         writer = cv2.VideoWriter(output_path, fourcc, self._source_fps or 25, (result.shape[1], result.shape[0]))
                     writer.write(result)
                 if real_show and cv2 is not None:
@@ -385,10 +397,8 @@ class VideoDetector:
                 break
             if frames % self.skip_frames == 0:
                 hold_detections = self.process(frame)
-                if self.action_id is not None and hold_detections is not None and self.tracker is not None:
-                    actions = self.action_id.update(hold_detections)
-                else:
-                    actions = []
+                if self._tracked:                          # video_detect.py:137-154; otherwise `actions` keeps its previous value
+                    actions = self.action_id.update(hold_detections) if self.action_id is not None else []
                 frames = 0
             else:
                 actions = []

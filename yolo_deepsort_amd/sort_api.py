@@ -154,7 +154,13 @@ class NearestNeighborDistanceMetric:
         self.samples = {k: self.samples[k] for k in active_targets}
 
     def distance(self, features, targets):
-        feats = _f32(features).reshape(-1, 512)
+        """nn_matching.py:158-187: cost matrix [len(targets), len(features)].  The embedding width is whatever the caller stores
+        (the reference is dimension agnostic); every gallery row must have the width of `features` (ValueError otherwise), and
+        the device kernel takes widths up to 512 (narrower rows are zero padded inside the library)."""
+        feats = _f32(features)
+        if feats.ndim != 2:
+            raise ValueError("features must be a [N, dim] matrix, got shape %r" % (feats.shape,))
+        dim = feats.shape[1]
         seg, rows = [0], []
         for t in targets:
             rows += self.samples[t]
@@ -162,10 +168,16 @@ class NearestNeighborDistanceMetric:
         out = np.zeros((len(targets), feats.shape[0]), np.float32)
         if not targets or not feats.shape[0]:
             return out
-        gal = np.ascontiguousarray(np.stack(rows, 0), dtype=np.float32)
+        bad = [r.shape for r in rows if r.shape != (dim,)]
+        if bad:
+            raise ValueError("gallery rows of width %s do not match features of width %d" % (sorted(set(b[0] for b in bad)), dim))
+        if not 1 <= dim <= 512:
+            raise ValueError("embedding width %d is outside what the device kernel takes (1..512)" % dim)
+        gal = np.ascontiguousarray(np.stack(rows, 0), dtype=np.float32) if rows else np.zeros((0, dim), np.float32)
         seg = np.asarray(seg, np.int32)
-        fn = _lib_ready().yds_cosine_min_cost if self.metric_name == "cosine" else _lib.load().yds_euclidean_min_cost
-        _lib.check(fn(_lib.ptr(gal), _lib.ptr(seg), len(targets), _lib.ptr(feats), feats.shape[0], 512, _lib.ptr(out)))
+        lib = _lib_ready()
+        fn = lib.yds_cosine_min_cost if self.metric_name == "cosine" else lib.yds_euclidean_min_cost
+        _lib.check(fn(_lib.ptr(gal), _lib.ptr(seg), len(targets), _lib.ptr(feats), feats.shape[0], dim, _lib.ptr(out)))
         return out
 
 
@@ -277,8 +289,11 @@ def gate_cost_matrix(kf, cost_matrix, tracks, detections, track_indices, detecti
 # ------------------------------------------------------------------------------------------ tracker.py
 class Tracker:
     """deep_sort/sort/tracker.py:8-176 on the device-resident tracker (yds_tracker_*): ``predict()`` then
-    ``update(detections)`` per frame, ``tracks`` as Track snapshots.  predict + update run as one fused launch sequence
-    inside update(); calling update() without predict() is refused (the reference would associate un-predicted states)."""
+    ``update(detections)`` per frame, ``tracks`` as Track snapshots.  On the device predict + update run as one fused launch
+    sequence inside update(); ``tracks`` read BETWEEN predict() and update() show the predicted states (the Kalman
+    prediction of the snapshot plus track.py:115-116's age / time_since_update increments), like the reference's list does.
+    Calling update() without predict() is refused (the reference would associate un-predicted states).  The appearance
+    galleries live in HBM (``metric.samples`` of the metric object handed in is not populated by this class)."""
 
     def __init__(self, metric, max_iou_distance=0.7, max_age=70, n_init=3, use_cuda=False):
         from .deep_sort import _TrackerHandle
@@ -300,14 +315,21 @@ class Tracker:
         tlwh = np.stack([x.tlwh for x in detections], 0) if d else np.zeros((0, 4), np.float32)
         feats = np.stack([x.feature for x in detections], 0) if d else np.zeros((0, 512), np.float32)
         payload = np.array([0.0 if x.payload is None else float(x.payload) for x in detections], np.float32)
+        if d and feats.shape[1] != 512:
+            raise ValueError("the device tracker stores 512-wide embeddings (deep_sort/deep/model.py:93), got %d" % feats.shape[1])
         self.last_rows = self._handle.step(tlwh, feats, payload)
 
     @property
     def tracks(self):
         st = self._handle.state()
         n = len(st["ids"])
-        pay = np.zeros(max(n, 1), np.float32)
+        pay, age = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.int32)
         if n:
             _lib.check(_lib.load().yds_tracker_get_payload(self._handle._h, _lib.ptr(pay), n))
-        return [Track(st["mean"][i:i + 1], st["cov"][i:i + 1], st["ids"][i], self.n_init, self.max_age, payload=float(pay[i]),
-                      hits=st["hits"][i], time_since_update=st["tsu"][i], state=st["state"][i]) for i in range(n)]
+            _lib.check(_lib.load().yds_tracker_get_age(self._handle._h, _lib.ptr(age), n))
+        mean, cov, tsu = st["mean"], st["cov"], st["tsu"]
+        if self._predicted and n:                     # between predict() and update(): track.py:105-116
+            mean, cov = self.kf.predict(mean, cov)
+            age, tsu = age + 1, tsu + 1
+        return [Track(mean[i:i + 1], cov[i:i + 1], st["ids"][i], self.n_init, self.max_age, payload=float(pay[i]),
+                      hits=st["hits"][i], age=age[i], time_since_update=tsu[i], state=st["state"][i]) for i in range(n)]
