@@ -164,7 +164,7 @@ def test_rccl_comm_world_of_one():
     try:
         assert lib.yds_comm_world(comm) == 1 and lib.yds_comm_rank(comm) == 0
         outs = [np.arange(12, dtype=np.int32).reshape(2, 6), None, np.zeros((0, 6), np.int32), np.full((256, 6), 7, np.int32)]
-        blk = dist.pack_rows(outs)
+        blk = dist.pack_rows(outs, dist.rows_for(256))
         back = np.zeros((1,) + blk.shape, np.int32)
         _lib.check(lib.yds_comm_allgather(comm, _lib.ptr(blk), blk.nbytes, _lib.ptr(back)))
         got = dist.unpack_rows(back[0])

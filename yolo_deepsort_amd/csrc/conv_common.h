@@ -103,13 +103,14 @@ struct FlatRows {
 // ONE_PASS: the staging area holds the WHOLE tile (BM x (BN+4) floats instead of one row of waves): every wave stores its
 // accumulators at once and the workgroup sweeps all rows after a single barrier (2 barriers instead of 2 x WM, no waves
 // idling while one wave row is staged).  The caller sizes the LDS for it (conv_stage_bytes).
-template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, class RowMap = FlatRows, bool ONE_PASS = false>
-__device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, RowMap rows, int n0, int tid) {
+// Store: callable (float *st) that writes THIS wave's accumulator tile into its band of the staging area (row r, column c of
+// the band at st[r * (BN + 4) + c]) - the only part that depends on the MFMA shape's C/D layout.
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int NT, class RowMap, bool ONE_PASS, class Store>
+__device__ __forceinline__ void conv_epilogue_core(const ConvKernelArgs &p, Store store, float *stage, RowMap rows, int n0, int tid) {
     constexpr int ROWS = BM / WM, LD = BN + 4, C4 = BN / 4;        // staged rows, padded row length, float4 per row
     constexpr int RSTEP = NT / C4;                                   // rows covered by one sweep of the NT threads
     static_assert(NT % C4 == 0 && C4 % 2 == 0 && ROWS % RSTEP == 0, "tile width must divide the workgroup; lane pairs share a row");
-    const int lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
-    const int col = lane & 31, rsel = (lane >> 5) * 4;
+    const int wave = tid >> 6, wm = wave / WN;
     const int c4 = tid % C4, rr = tid / C4;
     const int n = n0 + c4 * 4;
     const bool n_vec = n + 3 < p.Cout;
@@ -156,16 +157,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
         }
 #pragma unroll
         for (int pass = 0; pass < WM; ++pass) {
-            if (ONE_PASS ? pass == 0 : wm == pass) {
-                float *st = stage + (ONE_PASS ? wm * ROWS * LD : 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            st[(i * 32 + rsel + (e & 3) + 8 * (e >> 2)) * LD + wn * (BN / WN) + j * 32 + col] = acc[i][j][e];
-            }
+            if (ONE_PASS ? pass == 0 : wm == pass) store(stage + (ONE_PASS ? wm * ROWS * LD : 0));
             if (!ONE_PASS || pass == 0) __syncthreads();
 #pragma unroll
             for (int k2 = 0; k2 < PER_PASS; ++k2) {
@@ -227,6 +219,47 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x
 }
 constexpr size_t conv_stage_bytes(int BM, int BN) { return (size_t)BM * (BN + 4) * sizeof(float); }
 
+// 32x32 accumulator fragments (v_mfma_f32_32x32x*): col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, class RowMap = FlatRows, bool ONE_PASS = false>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, RowMap rows, int n0, int tid) {
+    constexpr int LD = BN + 4;
+    const int lane = tid & 63, wn = (tid >> 6) % WN;
+    const int col = lane & 31, rsel = (lane >> 5) * 4;
+    auto store = [&](float *st) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    st[(i * 32 + rsel + (e & 3) + 8 * (e >> 2)) * LD + wn * (BN / WN) + j * 32 + col] = acc[i][j][e];
+    };
+    conv_epilogue_core<BM, BN, WM, WN, ACT, RES, NT, RowMap, ONE_PASS>(p, store, stage, rows, n0, tid);
+}
+
+// 16x16 accumulator fragments (v_mfma_f32_16x16x32_f16): col = lane & 15, row = 4 * (lane >> 4) + e; TM / TN count 16-wide blocks.
+// (Bank check: the four 16-lane groups of a store sit 4 rows = 4 * (BN + 4) floats apart = 16 banks mod 64: conflict free.)
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, class RowMap = FlatRows, bool ONE_PASS = false>
+__device__ __forceinline__ void conv_epilogue16_rows(const ConvKernelArgs &p, f32x4 (&acc)[TM][TN], float *stage, RowMap rows, int n0, int tid) {
+    constexpr int LD = BN + 4;
+    const int lane = tid & 63, wn = (tid >> 6) % WN;
+    const int col = lane & 15, rsel = (lane >> 4) * 4;
+    auto store = [&](float *st) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    st[(i * 16 + rsel + e) * LD + wn * (BN / WN) + j * 16 + col] = acc[i][j][e];
+    };
+    conv_epilogue_core<BM, BN, WM, WN, ACT, RES, NT, RowMap, ONE_PASS>(p, store, stage, rows, n0, tid);
+}
+template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, bool ONE_PASS = false>
+__device__ __forceinline__ void conv_epilogue16(const ConvKernelArgs &p, f32x4 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
+    conv_epilogue16_rows<BM, BN, WM, WN, ACT, RES, TM, TN, NT, FlatRows, ONE_PASS>(p, acc, stage, FlatRows{m0}, n0, tid);
+}
+
 template <int BM, int BN, int WM, int WN, int ACT, int RES, int TM, int TN, int NT = 256, bool ONE_PASS = false>
 __device__ __forceinline__ void conv_epilogue(const ConvKernelArgs &p, f32x16 (&acc)[TM][TN], float *stage, int m0, int n0, int tid) {
     conv_epilogue_rows<BM, BN, WM, WN, ACT, RES, TM, TN, NT, FlatRows, ONE_PASS>(p, acc, stage, FlatRows{m0}, n0, tid);
@@ -278,6 +311,8 @@ const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
 // sampled (shader cycles, 100 MHz ticks) accumulated inside the window kernels since the last reset
 void conv_win_clock(unsigned long long *cycles_ticks, bool reset);
+void conv_win16_clock(unsigned long long *cycles_ticks, bool reset);
+void launch_conv_win16(ConvKernelArgs k, int shape, hipStream_t s);  // the f16x3 (default arithmetic) form on v_mfma_f32_16x16x32_f16 (conv_win16.hip)
 void conv_win2_clock(unsigned long long *cycles_ticks, bool reset);
 void conv_win2_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING2 builds: wait, barrier, body, prologue, epilogue, total cycles, steps, waves
 void conv_win_debug_prof(unsigned long long *out, bool reset);    // YDS_TIMING_WIN builds: prologue, K loop, epilogue cycles of the sampled workgroups, their count

@@ -533,6 +533,8 @@ void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
             YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
         }
+    } else if (!getenv("YDS_WIN32")) {                          // default arithmetic: the 16x16x32 form (YDS_WIN32=1: the 32x32x16 form, A/B runs)
+        launch_conv_win16(k, shape, s);
     } else if (shape == 0) {
 #define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)

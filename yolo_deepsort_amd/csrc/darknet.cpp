@@ -964,10 +964,11 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
 int yds_conv_clock(double *ghz, double *sampled_ms, int reset) {
     YDS_API_BEGIN
     YDS_HIP(hipDeviceSynchronize());
-    unsigned long long a[2], b[2];
+    unsigned long long a[2], b[2], c[2];
     yds::conv_win_clock(a, reset != 0);
     yds::conv_win2_clock(b, reset != 0);
-    const double cycles = (double)a[0] + (double)b[0], ticks = (double)a[1] + (double)b[1];
+    yds::conv_win16_clock(c, reset != 0);
+    const double cycles = (double)a[0] + (double)b[0] + (double)c[0], ticks = (double)a[1] + (double)b[1] + (double)c[1];
     if (ghz) *ghz = ticks > 0 ? cycles / ticks * 0.1 : 0.0;              // ticks are 10 ns
     if (sampled_ms) *sampled_ms = ticks * 1e-5;
     YDS_API_END
