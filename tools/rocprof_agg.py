@@ -12,7 +12,7 @@ from collections import OrderedDict
 
 
 def key_of(name):
-    m = re.match(r"void yds::(?:\(anonymous namespace\)::)?(conv3x3_f16x3_win2|conv3x3_f16x3_win|conv_igemm_f16x3_dma|conv_igemm_f16x3|conv_igemm_f32|conv3x3_rgb_direct|conv3x3_rgb_pool_mfma|conv3x3_rgb_pool|conv_stem2_f16x3|conv_block1_f16x3)<([^>]*)>", name)
+    m = re.match(r"void yds::(?:\(anonymous namespace\)::)?(conv3x3_f16x3_win16|conv3x3_f16x3_win2|conv3x3_f16x3_win|conv_igemm_f16x3_dma|conv_igemm_f16x3|conv_igemm_f32|conv3x3_rgb_direct|conv3x3_rgb_pool_mfma|conv3x3_rgb_pool|conv_stem2_f16x3|conv_block1_f16x3)<([^>]*)>", name)
     if not m:
         return None
     kind, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
@@ -22,6 +22,8 @@ def key_of(name):
         return f"{kind}<{args[0]},{args[1]},{args[2]}x{args[3]},{args[4]}>"
     if kind == "conv3x3_f16x3_win2":
         return f"{kind}<128,128,2x2>"
+    if kind == "conv3x3_f16x3_win16":       # the default-arithmetic form of the window kernel (16x16x32 MFMA): same tile variant name as bench.py's
+        return f"conv3x3_f16x3_win<256,{args[0]},{args[1]}x{args[2]}>"
     if kind == "conv3x3_f16x3_win":
         return f"{kind}<256,{args[0]},{args[1]}x{args[2]}>"
     if kind == "conv_igemm_f32":

@@ -315,7 +315,6 @@ void conv_win16_clock(unsigned long long *cycles_ticks, bool reset);
 void launch_conv_win16(ConvKernelArgs k, int shape, hipStream_t s);  // the f16x3 (default arithmetic) form on v_mfma_f32_16x16x32_f16 (conv_win16.hip)
 void conv_win2_clock(unsigned long long *cycles_ticks, bool reset);
 void conv_win2_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING2 builds: wait, barrier, body, prologue, epilogue, total cycles, steps, waves
-void conv_win_debug_prof(unsigned long long *out, bool reset);    // YDS_TIMING_WIN builds: prologue, K loop, epilogue cycles of the sampled workgroups, their count
 void conv_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING builds: wait / barrier / body / total cycles, steps, waves
 
 }  // namespace yds

@@ -17,19 +17,6 @@
 // address of the DMA and again by the fragment reads; 16 consecutive rows hit 16 distinct bank slots at any base.
 #include "conv_common.h"
 
-#ifndef YDS_WIN_AMAJOR
-#define YDS_WIN_AMAJOR 0
-#endif
-#ifndef YDS_WIN_X8_ABL
-#define YDS_WIN_X8_ABL 0   // experiment builds of the cross8 step: 1 no in-loop window conversion, 2 no fp8 MFMAs
-#endif
-#ifndef YDS_WIN_DEEP
-#define YDS_WIN_DEEP 0     // experiment (no gain, profiles/r03_fp8_cross.txt): the filter stage of step t+3, not t+2, is requested during step t
-#endif
-#ifndef YDS_WIN_ABL
-#define YDS_WIN_ABL 0      // experiment builds: 1 no DMA in the K loop, 2 + no fragment reads, 3 no MFMA, 4 no barrier / vmcnt wait, 5 no K loop
-#endif
-
 namespace yds {
 
 // TERMS == 2 ("cross8", opt in: yds_set_conv_cross8 / YDS_CONV_CROSS8=1): the hi x hi term stays on the fp16 pipe, the two cross
@@ -53,11 +40,6 @@ typedef short s2v __attribute__((ext_vector_type(2)));
 // 100 MHz counter (s_memrealtime) at its start and end; cycles / ticks is the clock the chip really ran at while every CU
 // was busy with this kernel (it is power limited: ~1.55 GHz, not the 2.4 GHz the MFMA peak is quoted at).
 __device__ unsigned long long yds_clk_win[2];
-#ifndef YDS_TIMING_WIN
-#define YDS_TIMING_WIN 0   // experiment: s_memtime stamps of the sampled workgroups' wave 0: prologue, K loop, epilogue cycles, count
-#endif
-__device__ unsigned long long yds_prof_win[8];
-
 namespace {
 
 constexpr int BM = 256, NW = 8, NT = NW * 64;
@@ -77,6 +59,7 @@ constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 template <int BN, int WM, int WN, int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows, int nbuf) {
     static_assert(WM * WN == NW, "eight waves");
+    static_assert(TERMS == 1 || TERMS == 2 || TERMS == 4, "the default arithmetic (three fp16 terms) is conv_win16.hip's kernel");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int B_STAGE = BN * ROW;
     constexpr int B_INST = BN / (8 * NW);      // filter DMA instructions per wave per stage (8 rows each)
@@ -179,21 +162,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         }
     };
     auto mfma = [&](int s, int m0) {
-#if YDS_WIN_AMAJOR
-        // experiment: operand-major order - consecutive MFMAs keep their A operand (Ah_i x {Bh_j, Bl_j}..., then Al_i x {Bh_j}...)
-        int m = m0;
-        {
-            const int per_i = 3 * TN, i = m0 / per_i, r = m0 % per_i;
-            if (r < 2 * TN) m = (i * TN + r / 2) * 3 + (r & 1);          // Ah_i x Bh_j (term 0), Ah_i x Bl_j (term 1)
-            else m = (i * TN + (r - 2 * TN)) * 3 + 2;                      // Al_i x Bh_j (term 2)
-        }
-#else
         const int m = m0;
-#endif
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
         if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[s][2 * i], al = fr[s][2 * i + 1], bh = fr[s][2 * (TM + j)], bl = fr[s][2 * (TM + j) + 1];
-        if (YDS_WIN_ABL == 3) { acc1[i][j][term] += (float)ah[0] + (float)al[1] + (float)bh[2] + (float)bl[3]; return; }
         if (TERMS == 4) {                                        // both slots hold hi values (of two channel groups)
             if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
             else if (term == 1) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, acc1[i][j], 0, 0, 0);
@@ -234,28 +206,23 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     auto step = [&](int g, auto tap_c, auto last_c) {
         constexpr int TAP = decltype(tap_c)::value;
         constexpr bool LAST = decltype(last_c)::value;          // last channel group: no window prefetch, filter refills stop
-        constexpr int AHEAD = YDS_WIN_DEEP ? 3 : 2;             // prefetch distance of the filter stages, in steps
+        constexpr int AHEAD = 2;             // prefetch distance of the filter stages, in steps
         constexpr bool REFILL = !(LAST && TAP + AHEAD > 8);     // a step t+AHEAD exists
         constexpr bool NEXT = !(LAST && TAP == 8);              // a step t+1 exists
         constexpr int TAP1 = (TAP + 1) % 9, TAP2 = (TAP + AHEAD) % 9;
         constexpr int OPS = (1 + B_INST + NF + NM - 1) / NM;    // memory operations per substep-1 slot
         static_assert(NF <= NM, "not enough MFMA slots in substep 0");
         const int g1 = TAP + 1 >= 9 ? g + 1 : g, g2 = TAP + AHEAD >= 9 ? g + 1 : g;
-        // DMA instructions the PREVIOUS step issued (its window piece + its filter pieces): with the deep prefetch they may still be
-        // in flight at this step's barrier - what must have landed is the stage of step t+1, requested a step earlier
-        constexpr int PREV_DMA = !YDS_WIN_DEEP ? 0 : TAP == 0 ? B_INST : ((!LAST && TAP - 1 < APW) ? 1 : 0) + (!(LAST && TAP - 1 + AHEAD > 8) ? B_INST : 0);
         const char *bst = bring + (TAP % NSB) * B_STAGE, *bst1 = bring + ((TAP + 1) % NSB) * B_STAGE;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             mfma(0, m);
             __builtin_amdgcn_sched_barrier(0);
-            if (m < NF && YDS_WIN_ABL != 2) frag_read(bst, 1, frag_order(m));
+            if (m < NF) frag_read(bst, 1, frag_order(m));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (YDS_WIN_ABL != 4) {
-            wait_vmcnt<PREV_DMA>();
-            __builtin_amdgcn_s_barrier();
-        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         if (NEXT) tap_addr(g1, TAP1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -264,10 +231,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int o = m * OPS; o < (m + 1) * OPS; ++o) {     // memory operations of this slot
-                constexpr bool DMA = YDS_WIN_ABL != 1 && YDS_WIN_ABL != 2;
-                if (o == 0) { if (DMA && !LAST && TAP < APW) a_piece(g + 1, TAP); }
-                else if (o - 1 < B_INST) { if (DMA && REFILL) b_piece(g2, TAP2, (TAP + AHEAD) % NSB, o - 1); }
-                else if (o - 1 - B_INST < NF) { if (NEXT && YDS_WIN_ABL != 2) frag_read(bst1, 0, o - 1 - B_INST); }
+                if (o == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
+                else if (o - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + AHEAD) % NSB, o - 1); }
+                else if (o - 1 - B_INST < NF) { if (NEXT) frag_read(bst1, 0, o - 1 - B_INST); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -330,12 +296,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     auto step8 = [&](int g, auto tap_c, auto last_c) {
         constexpr int TAP = decltype(tap_c)::value;
         constexpr bool LAST = decltype(last_c)::value;
-        constexpr int AHEAD = YDS_WIN_DEEP ? 3 : 2;
+        constexpr int AHEAD = 2;
         constexpr bool REFILL = !(LAST && TAP + AHEAD > 8);
         constexpr bool NEXT = !(LAST && TAP == 8);
         constexpr int TAP1 = (TAP + 1) % 9, TAP2 = (TAP + AHEAD) % 9;
         // (the window of group g+1 is converted after step 7: every one of its pieces has to be in LDS at that step's barrier)
-        constexpr int PREV_DMA = !YDS_WIN_DEEP || (TAP == 7 && !LAST) ? 0 : TAP == 0 ? B_INST : ((!LAST && TAP - 1 < APW) ? 1 : 0) + (!(LAST && TAP - 1 + AHEAD > 8) ? B_INST : 0);
         constexpr int NH = 2 * (TM + TN), NX = TM * TN, NHH = 2 * TM * TN;
         constexpr int OPS = (1 + B_INST + NH + NX - 1) / NX;
         constexpr int XR = (NH + NHH - 1) / NHH;                // fp8 fragment halves per substep-0 slot (1; 2 for the 64-filter tiles)
@@ -348,34 +313,31 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = m * XR; r < (m + 1) * XR; ++r)
-                if (r < NH && YDS_WIN_ABL != 2) x_read(bst, frag_order(r));
+                if (r < NH) x_read(bst, frag_order(r));
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (YDS_WIN_ABL != 4) {
-            wait_vmcnt<PREV_DMA>();
-            __builtin_amdgcn_s_barrier();
-        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         if (NEXT) tap_addr(g1, TAP1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < NX; ++m) {
             const int i = m / TN, j = m % TN;
-            if (YDS_WIN_X8_ABL != 2) acc1[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[i], xb[j], acc1[i][j], 0, 0, 0, scale_a, 0, scale_b);
+            acc1[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[i], xb[j], acc1[i][j], 0, 0, 0, scale_a, 0, scale_b);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int o = m * OPS; o < (m + 1) * OPS; ++o) {
-                constexpr bool DMA = YDS_WIN_ABL != 1 && YDS_WIN_ABL != 2;
-                if (o == 0) { if (DMA && !LAST && TAP < APW) a_piece(g + 1, TAP); }
-                else if (o - 1 < B_INST) { if (DMA && REFILL) b_piece(g2, TAP2, (TAP + AHEAD) % NSB, o - 1); }
+                if (o == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
+                else if (o - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + AHEAD) % NSB, o - 1); }
                 else if (o - 1 - B_INST < NH) {
                     // fp16 fragments of step t+1 in the order its MFMAs need them: k16 block 0 of A0, B0, B1, A1, then block 1
                     constexpr int order[8] = {0, 2 * TM, 2 * TM + 2, 2, 1, 2 * TM + 1, 2 * TM + 3, 3};
-                    if (NEXT && YDS_WIN_ABL != 2) hi_read(bst1, TM == 2 && TN == 2 ? order[o - 1 - B_INST] : o - 1 - B_INST);
+                    if (NEXT) hi_read(bst1, TM == 2 && TN == 2 ? order[o - 1 - B_INST] : o - 1 - B_INST);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (TAP == 7 && !LAST && YDS_WIN_X8_ABL != 1) convert_window((g + 1) & 1);
+        if (TAP == 7 && !LAST) convert_window((g + 1) & 1);
     };
     auto group = [&](int g, auto last_c) {
         if constexpr (TERMS == 2) {
@@ -402,11 +364,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     for (int b = 0; b < B_INST; ++b) b_piece(0, 0, 0, b);
 #pragma unroll
     for (int b = 0; b < B_INST; ++b) b_piece(0, 1, 1, b);
-    if (YDS_WIN_DEEP) {
-#pragma unroll
-        for (int b = 0; b < B_INST; ++b) b_piece(0, 2, 2, b);
-    }
-    wait_vmcnt<(YDS_WIN_DEEP ? 2 : 1) * B_INST>();              // later stages may still be in flight: the mid-step waits cover them
+    wait_vmcnt<B_INST>();              // later stages may still be in flight: the mid-step waits cover them
     __syncthreads();                                            // window 0, stage 0 and the zero row are in LDS
     if (TERMS == 2) {
         convert_window(0);
@@ -422,30 +380,18 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    unsigned long long ph_pro = 0, ph_loop = 0;
-    if (YDS_TIMING_WIN && clk_sample) ph_pro = __builtin_amdgcn_s_memtime();
-    if (YDS_WIN_ABL != 5) {                                     // ablation 5: prologue + epilogue only
-        for (int g = 0; g + 1 < G; ++g) group(g, std::false_type{});
-        group(G - 1, std::true_type{});
-    }
+    for (int g = 0; g + 1 < G; ++g) group(g, std::false_type{});
+    group(G - 1, std::true_type{});
 
     __syncthreads();                                            // every wave is done with the window and the ring
-    if (YDS_TIMING_WIN && clk_sample) ph_loop = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                acc1[i][j][e] = TERMS != 3 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
+                acc1[i][j][e] *= 1.f / A_SCALE;                       // every tier of this kernel keeps one accumulator set
     conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT, true>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);   // whole-tile staging
-    if (YDS_TIMING_WIN && clk_sample) {
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        atomicAdd(&yds_prof_win[0], ph_pro - clk_c0);
-        atomicAdd(&yds_prof_win[1], ph_loop - ph_pro);
-        atomicAdd(&yds_prof_win[2], t - ph_loop);
-        atomicAdd(&yds_prof_win[3], 1ull);
-    }
     if (clk_sample) {
         atomicAdd(&yds_clk_win[0], __builtin_amdgcn_s_memtime() - clk_c0);
         atomicAdd(&yds_clk_win[1], wall_clock64() - clk_w0);
@@ -454,7 +400,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
 
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
 
-template <int BN, int WM, int WN, int ACT, int RES, int TERMS = 3> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
+template <int BN, int WM, int WN, int ACT, int RES, int TERMS> void launch_inst_win(ConvKernelArgs k, hipStream_t s) {
     const int wrows = window_rows(k.W), nbuf = k.Cin == (TERMS == 4 ? 64 : 32) ? 1 : 2;
     // (the epilogue stages the whole 256 x BN tile in the same LDS: narrow images need more than their windows + ring)
     const size_t smem = std::max((size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW, conv_stage_bytes(BM, BN));
@@ -470,14 +416,6 @@ template <int BN, int WM, int WN, int ACT, int RES, int TERMS = 3> void launch_i
 }
 
 }  // namespace
-
-void conv_win_debug_prof(unsigned long long *out, bool reset) {
-    YDS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(yds_prof_win), 8 * sizeof(unsigned long long)));
-    if (reset) {
-        unsigned long long z[8] = {};
-        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_prof_win), z, sizeof z));
-    }
-}
 
 void conv_win_clock(unsigned long long *cycles_ticks, bool reset) {
     YDS_HIP(hipMemcpyFromSymbol(cycles_ticks, HIP_SYMBOL(yds_clk_win), 2 * sizeof(unsigned long long)));
@@ -533,20 +471,8 @@ void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
             YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
         }
-    } else if (!getenv("YDS_WIN32")) {                          // default arithmetic: the 16x16x32 form (YDS_WIN32=1: the 32x32x16 form, A/B runs)
+    } else {                                                     // default arithmetic: the v_mfma_f32_16x16x32_f16 form (conv_win16.hip)
         launch_conv_win16(k, shape, s);
-    } else if (shape == 0) {
-#define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R>(k, s)
-        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
-#undef YDS_CALL
-    } else if (shape == 1) {
-#define YDS_CALL(A, R) launch_inst_win<64, 8, 1, A, R>(k, s)
-        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
-#undef YDS_CALL
-    } else {
-#define YDS_CALL(A, R) launch_inst_win<64, 4, 2, A, R>(k, s)
-        YDS_DISPATCH_ACT_RES(k, YDS_CALL)
-#undef YDS_CALL
     }
 }
 

@@ -13,26 +13,20 @@
 // the step is split SPATIALLY instead of into two K halves: the wave's blocks of 16 rows / 16 filters form two halves,
 //     H0 = A blocks [0, TM/2) + B blocks [0, TN/2),   H1 = the rest,
 // and the accumulator tile four quadrants Qab = (A half a) x (B half b):
-//     phase A   Q00 on H0 (read during the previous step)                       slots: this step's H1 fragments
-//     mid       s_waitcnt vmcnt(0) + s_barrier: stage t+1 (and a new group's window) landed, every wave is done with step t-1
-//     phase B   Q01, Q10                                                         slots: window piece of group g+1, filter pieces of step t+2
-//     phase C   Q11                                                              slots: H0 of step t+1 (its registers are free now)
+//     Q00   on H0 (read during the previous step)                 slots: this step's B fragments of H1
+//     Q01                                                               slots: this step's A fragments of H1
+//     mid   s_waitcnt vmcnt(0) + s_barrier: stage t+1 (and a new group's window) landed, every wave is done with step t-1
+//     Q10                                                               slots: window piece of group g+1, filter pieces of step t+2,
+//                                                                              then the A fragments of H0 of step t+1 (free since Q01)
+//     Q11                                                               slots: the B fragments of H0 of step t+1 (free since Q10)
+// Inside a quadrant the MFMAs run term-major (all hi x hi, all hi x lo, all lo x hi): no back-to-back accumulation into one
+// tile.  Measured against the 32x32x16 kernel on the same box (profiles/r04_win16_ab.txt): 3-6 % faster on the 128-filter tiles,
+// 1-3 % on the 64-filter ReID tiles - after the per-step address work was cut to one register per block (a first build with two
+// and 22 spilled VGPRs was 9 % SLOWER: the step is as much issue bound as power bound).
 // Fragments: lane l holds 8 consecutive channels (chunk l >> 4 of the hi or lo half) of row l & 15 of its block - the 16 lanes
 // of one chunk read 16 consecutive rows, which the swizzle spreads over 16 distinct 16-byte bank slots at any base.
 // C/D layout of the instruction: column (filter) = lane & 15, row (pixel) = 4 * (lane >> 4) + e, e = 0..3.
 #include "conv_common.h"
-
-#ifndef W16_ORDER
-#define W16_ORDER 0      // experiment: 1 = term-major MFMA order inside a quadrant (no back-to-back accumulation into one tile)
-#endif
-#ifndef W16_PIN
-#define W16_PIN 1        // experiment: 0 = no sched_barrier pinning inside the phases
-#endif
-#if W16_PIN
-#define W16_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define W16_FENCE() do {} while (0)
-#endif
 
 namespace yds {
 
@@ -148,13 +142,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win16(ConvKernelArgs p, i
             if (g & 1) bl[j] = v; else bh[j] = v;
         }
     };
-    // H1 fragments in the order phase B needs them (Q01 first: the B half), H0 fragments of the next step in the order Q00 does
-    auto h1_order = [&](int k) { return k < 2 * HN ? 2 * HM + k : k - 2 * HN; };
     constexpr int NRH = 2 * (HM + HN);                           // fragment reads per half
     constexpr int NMQ = 3 * HM * HN;                             // MFMAs per quadrant
-    static_assert(NRH <= NMQ, "one memory operation per MFMA slot");
     auto mfma = [&](int qa, int qb, int m) {                     // MFMA m of quadrant (A half qa) x (B half qb)
-        const int ij = W16_ORDER ? m % (HM * HN) : m / 3, term = W16_ORDER ? m / (HM * HN) : m % 3, i = qa * HM + ij / HN, j = qb * HN + ij % HN;
+        const int ij = m % (HM * HN), term = m / (HM * HN), i = qa * HM + ij / HN, j = qb * HN + ij % HN;   // term-major: no back-to-back accumulation into one tile
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
         else if (term == 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
         else acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
@@ -179,34 +170,46 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win16(ConvKernelArgs p, i
         constexpr int TAP1 = (TAP + 1) % 9, TAP2 = (TAP + 2) % 9;
         const int g1 = TAP + 1 >= 9 ? g + 1 : g, g2 = TAP + 2 >= 9 ? g + 1 : g;
         const char *bst = bring + (TAP % NSB) * B_STAGE, *bst1 = bring + ((TAP + 1) % NSB) * B_STAGE;
-        // phase A: Q00, this step's H1 fragments in its slots
+        auto dma = [&](int o) {                                  // DMA operation o of this step (window piece, then the filter pieces)
+            if (o == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
+            else if (o - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + 2) % NSB, o - 1); }
+        };
+        constexpr int NA = 2 * HM, NB = 2 * HN;                 // A / B fragment reads of one half (A fragments are f < NA)
+        // Q00: this step's B fragments of half 1; Q01: its A fragments of half 1
 #pragma unroll
         for (int m = 0; m < NMQ; ++m) {
             mfma(0, 0, m);
-            W16_FENCE();
-            if (m < NRH) frag_read(bst, 1, h1_order(m));
-            W16_FENCE();
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < NB) frag_read(bst, 1, NA + m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < NMQ; ++m) {
+            mfma(0, 1, m);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m < NA) frag_read(bst, 1, m);
+            __builtin_amdgcn_sched_barrier(0);
         }
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (NEXT) tap_addr(g1, TAP1);
         __builtin_amdgcn_sched_barrier(0);
-        // phase B: Q01, Q10, the DMA pieces in the first slots
+        // Q10: the DMA pieces, then the next step's A fragments of half 0 (free since Q01); Q11: its B fragments of half 0
 #pragma unroll
-        for (int m = 0; m < 2 * NMQ; ++m) {
-            if (m < NMQ) mfma(0, 1, m); else mfma(1, 0, m - NMQ);
-            W16_FENCE();
-            if (m == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
-            else if (m - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + 2) % NSB, m - 1); }
-            W16_FENCE();
+        for (int m = 0; m < NMQ; ++m) {
+            mfma(1, 0, m);
+            __builtin_amdgcn_sched_barrier(0);
+            if (m <= B_INST) dma(m);
+            else if (NEXT && m - 1 - B_INST < NA) frag_read(bst1, 0, m - 1 - B_INST);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // phase C: Q11, the H0 fragments of step t+1 in its slots
+        static_assert(1 + B_INST + NA <= NMQ, "Q10 holds the DMA pieces and the A fragments");
 #pragma unroll
         for (int m = 0; m < NMQ; ++m) {
             mfma(1, 1, m);
-            W16_FENCE();
-            if (NEXT && m < NRH) frag_read(bst1, 0, m);
-            W16_FENCE();
+            __builtin_amdgcn_sched_barrier(0);
+            if (NEXT && m < NB) frag_read(bst1, 0, NA + m);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     auto group = [&](int g, auto last_c) {

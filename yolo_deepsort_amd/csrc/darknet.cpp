@@ -976,8 +976,7 @@ int yds_conv_clock(double *ghz, double *sampled_ms, int reset) {
 int yds_debug_prof(uint64_t *out8, int reset) {
     YDS_API_BEGIN
     unsigned long long v[8];
-    if (reset & 4) yds::conv_win_debug_prof(v, (reset & 1) != 0);        // bit 2: the 512-thread window kernel's phase stamps
-    else if (reset & 2) yds::conv_win2_debug_prof(v, (reset & 1) != 0);      // bit 1: the two-workgroup window kernel's counters
+    if (reset & 2) yds::conv_win2_debug_prof(v, (reset & 1) != 0);      // bit 1: the two-workgroup window kernel's counters
     else yds::conv_debug_prof(v, reset != 0);
     for (int i = 0; i < 8; ++i) out8[i] = v[i];
     YDS_API_END
