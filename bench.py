@@ -184,12 +184,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")
-    ap.add_argument("--cross8-detector-only", action="store_true", help="with --cross8: the ReID network keeps the default arithmetic (track ids of crowd scenes unchanged)")
     ap.add_argument("--math", default="f16x3", choices=["f16x3", "f32"], help="conv arithmetic of the WHOLE run: f16x3 (default: split-fp16 operands, exact products, "
                                                                               "fp32 accumulate) or f32 (exact fp32 MFMA kernels; profiles of the value_f32_math leg)")
-    ap.add_argument("--value-cross8", action="store_true", help="add a short leg in the opt-in cross8 tier (detector only) and report it as value_cross8")
-    ap.add_argument("--cross8", action="store_true", help="opt-in tier: the window 3x3 kernel computes the cross terms of the f16x3 product in fp8 e4m3 "
-                                                          "(models.set_conv_cross8; not the metric's arithmetic: heads move by ~1e-5 of their maximum)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` on its own launches the N ranks itself (one process per GPU, rendezvous on 127.0.0.1);
@@ -228,8 +224,6 @@ def main():
         raise SystemExit(3)
     if args.math == "f32":
         lib.yds_set_conv_math(0)
-    if args.cross8:
-        _lib.check(lib.yds_set_conv_cross8(2 if args.cross8_detector_only else 1))
     wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
     cfg = wl.cfg
     wl.to_device()
@@ -259,8 +253,6 @@ def main():
     math_name = {0: "f32", 1: "f16x3", 2: "f16"}[lib.yds_get_conv_math()] if not args.half else "f16"
     # dtype: the arithmetic type the conv path computes in.  f16x3 = both operands as two-term fp16 expansions (22 significant bits), exact
     # fp16 products, fp32 accumulation - the reference's fp32 class; f32 = v_mfma_f32_32x32x2_f32
-    if args.cross8 and math_name == "f16x3":
-        math_name = "f16x3, window 3x3 kernel: fp16 hi x hi + fp8 e4m3 cross terms"
 
     # ---- the same steps with the frames coming from pinned host memory (PCIe inside the timed region)
     dt_up = None
@@ -272,13 +264,9 @@ def main():
         # (every rank runs the leg - its steps contain the exchange step - rank 0 reports)
         f16x3 = lib.yds_get_conv_math() == 1 and not args.half
         peak = PEAK_F16_MFMA_TFLOPS / 3 if f16x3 else (PEAK_F16_MFMA_TFLOPS if args.half else PEAK_F32_MFMA_TFLOPS)
-        x8 = args.cross8 and f16x3
-        # cross8: the window kernel's own bound is 128 instead of 192 pipe cycles per 32 channels and accumulator tile
-        peak_of = (lambda name: PEAK_F16_MFMA_TFLOPS / 2 if x8 and name.startswith("conv3x3_f16x3_win<256,128") else peak)
-        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, 2 * (W + K), peak, peak_of)
+        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, 2 * (W + K), peak)
         if rank == 0 and dom is not None:
-            note = ("cross8: two fp16 MFMAs + one fp8 K=64 MFMA per 32 channels = 2500 / 2 TFLOP/s fp32-equivalent (the other kernels: 2500 / 3)"
-                    if dom["peak"] != peak else "dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
+            note = ("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
                     else ("dense fp16 MFMA" if args.half else "fp32-input MFMA, 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz"))
             roofline = roofline_json(dom, allc, B, note, committed_traffic(args.config, dom["kernel"], B, "_f32" if math_name == "f32" else ""))
             roofline.update(
@@ -328,7 +316,7 @@ def main():
 
     # ---- exact-fp32 kernels (the reference's own arithmetic), short run; the network is re-planned: tensor formats depend on the
     #      conv math.  Its roofline block is measured like the default one, against the fp32-input MFMA peak.
-    f32_fps, roofline_f32, value_cross8 = None, None, None
+    f32_fps, roofline_f32 = None, None
     if not args.no_extras and not args.half and math_name != "f32":
         del wl
         sync()
@@ -347,16 +335,6 @@ def main():
                 roofline_f32["value_f32_math"] = round(f32_fps, 2)
         del wl32
         lib.yds_set_conv_math(1)
-        # ---- the opt-in cross8 tier (detector only: the ReID network keeps the default arithmetic, so features and track ids are
-        #      those of the default mode; tests/test_gpu_bench_shape.py runs the parity test in this mode) - reported, never `value`
-        if args.value_cross8 and not args.cross8:
-            _lib.check(lib.yds_set_conv_cross8(2))
-            wlx = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base))
-            wlx.to_device()
-            dtx, _ = timed_steps(wlx, ranks, sync, k32, 2, 0, host_frames=False)
-            value_cross8 = ranks.total_frames(k32, B) / dtx
-            del wlx
-            _lib.check(lib.yds_set_conv_cross8(0))
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:      # rank 0 at N = 1 only (bench contract)
@@ -386,9 +364,6 @@ def main():
                 "RCCL via yds_comm_*" if ranks.comm is not None else ("gloo" + (f"; RCCL unavailable: {ranks.fallback_reason}" if ranks.fallback_reason else ""))),
             "stage_us_last_step": {k: round(v, 1) for k, v in stage.items()},
             "algorithmic_gflop_per_frame": round(flops_frame / 1e9, 2),
-            "value_cross8": None if value_cross8 is None else round(value_cross8, 2),
-            "value_cross8_note": "opt-in tier, detector only (models.set_conv_cross8(True, reid=False)): fp8 cross terms in the window 3x3 kernel, heads within 1e-3, "
-                                 "track ids those of the default mode; never the metric's arithmetic",
             "roofline": roofline, "roofline_f32": roofline_f32, "power_experiment": power, "conv_variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

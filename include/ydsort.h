@@ -256,15 +256,6 @@ int yds_conv_num_variants(void);
  * relative).  Default 1; env YDS_CONV_MATH=f32|f16x3 overrides the default. */
 int yds_set_conv_math(int mode);
 int yds_get_conv_math(void);
-/* Opt-in precision tier between the default and half=True (no reference counterpart; models.py runs fp32 or .half()): the
- * window-resident 3x3 convolution kernel keeps the hi x hi term of the split-fp16 product on the fp16 matrix pipe and computes
- * the two cross terms in fp8 e4m3 (one K=64 MFMA per 32 channels instead of four fp16 ones).  Detector heads move by 2-5e-5 of
- * their maximum (default mode: 2e-6, half: 1e-3).  Process wide like yds_set_conv_math.  mode 0 = off, 1 = detectors and the ReID
- * network, 2 = detectors only: ReID features, appearance costs and hence the track ids of crowded scenes stay those of the default
- * mode (with mode 1 the 1e-5 feature differences flip near-tie assignments among 200 tracks after some frames).  Env
- * YDS_CONV_CROSS8=1|2 sets the initial value; yds_get_conv_cross8 returns the mode. */
-int yds_set_conv_cross8(int mode);
-int yds_get_conv_cross8(void);
 const char *yds_conv_variant_name(int variant);
 /* Kernel tuning aid: time `iters` launches of one conv layer on random data (HIP events); returns the
  * average launch duration in us and the tile variant that was picked. */

@@ -261,43 +261,6 @@ def test_reid_larger_batch_vs_oracle():
         np.testing.assert_allclose(ex.forward(x[:d]), oreid.reid_forward(x[:d], sd), rtol=RTOL, atol=1e-5)
 
 
-def test_cross8_modes_and_the_reid_network():
-    """models.set_conv_cross8: mode 1 includes the ReID network (features move by ~1e-5, still inside the default tolerance
-    against the oracle), mode 2 (reid=False) leaves it in the default arithmetic - bit-identical features, hence the same
-    appearance costs and track ids as the default mode (bench.py --cross8 on the crowd stream: ids of 377 of 640 frames
-    survive mode 1, all 640 survive mode 2 / half mode; the 30-person stream keeps all 640 in every mode)."""
-    from oracle import reid as oreid
-    from yolo_deepsort_amd import _lib, models
-    from yolo_deepsort_amd.deep_sort import Extractor
-    import ctypes as C
-    import os
-    lib = _lib.load()
-    lib.yds_conv_variant_name.restype = C.c_char_p
-    win = [v for v in range(lib.yds_conv_num_variants()) if lib.yds_conv_variant_name(v) == b"conv3x3_f16x3_win<256,128,4x2>"][0]
-    sd = synth.reid_state_dict(1)
-    ex = Extractor(sd, max_crops=64)
-    x = np.random.RandomState(5).randn(48, 3, 128, 64).astype(F32)
-    prev = lib.yds_get_conv_cross8()
-    os.environ["YDS_CONV_FORCE"] = str(win)                  # (48 crops: the planner's timing would pick other kernels)
-    try:
-        models.set_conv_cross8(False)
-        base = np.array(ex.forward(x))
-        models.set_conv_cross8(True, reid=False)
-        assert models.get_conv_cross8() == 2
-        det_only = np.array(ex.forward(x))
-        models.set_conv_cross8(True)
-        assert models.get_conv_cross8() == 1
-        both = np.array(ex.forward(x))
-    finally:
-        lib.yds_set_conv_cross8(prev)
-        del os.environ["YDS_CONV_FORCE"]
-    assert np.array_equal(base, det_only)
-    d = float(np.abs(both - base).max())
-    assert 0 < d < 2e-4, d
-    np.testing.assert_allclose(both, oreid.reid_forward(x, sd), rtol=RTOL, atol=2e-4)
-
-
-# ----------------------------------------------------------------------------------------- Kalman
 def test_kalman_kernels_vs_golden():
     L = _lib()
     lib = L.load()

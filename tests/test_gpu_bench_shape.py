@@ -26,19 +26,6 @@ def test_pipeline_at_bench_shape_vs_reference(config):
     _bench_shape(config)
 
 
-def test_pipeline_at_bench_shape_cross8_detector_only():
-    """The opt-in cross8 tier (models.set_conv_cross8(True, reid=False), bench.py --value-cross8): fp8 cross terms in the detector's
-    window 3x3 kernels, the ReID network in the default arithmetic.  Held to the SAME reference fixture and tolerances as the default
-    mode on the metric's configuration (VERDICT r3 #8: the claim is checked inside -m gpu or dropped)."""
-    from yolo_deepsort_amd import models
-    models.set_conv_cross8(True, reid=False)
-    try:
-        assert models.get_conv_cross8() == 2
-        _bench_shape("cfg2")
-    finally:
-        models.set_conv_cross8(False)
-
-
 def _bench_shape(config):
     from yolo_deepsort_amd.workload import Workload, CONF_THRES, NMS_THRES
     g = golden(f"bench_shape_{config}")

@@ -73,6 +73,8 @@ CASES = [  # n, h, w, cin, cout, k, s, act, res_mode
     (1, 12, 304, 32, 64, 3, 1, "leaky", 1),           # one channel group: single window buffer, wide image
     (2, 38, 38, 64, 256, 3, 1, "mish", 1),            # two N tiles, four half groups, 2 x 1444 pixels: tiles straddle the image boundary
     (1, 120, 127, 32, 128, 3, 1, "leaky", 0),         # widest image the two-workgroup window kernel takes (384 window rows)
+    (3, 64, 32, 64, 64, 3, 1, "relu", 0),             # ReID layer1 shape: the 128x64 tile (two workgroups per CU), tiles cross crops
+    (2, 30, 43, 96, 48, 3, 1, "leaky", 1),            # its widest image (216 window rows), three channel groups, ragged filters
 ]
 
 
@@ -110,14 +112,15 @@ def test_every_conv_variant_vs_float64(math):
                         assert "split-K does not apply" in str(e), (names[v], str(e))
                         continue
                     assert "window-resident" in str(e), (names[v], str(e))
-                    assert not (k == 3 and s == 1) or ("win2" in names[v] and wd > 127), (names[v], str(e))
+                    small = "win<128,64" in names[v] and (cout > 64 or wd > 43)      # the 128x64 tile: 64-filter layers, W <= 43
+                    assert not (k == 3 and s == 1) or ("win2" in names[v] and wd > 127) or small, (names[v], str(e))
                     continue
                 err = float(np.abs(got - want).max()) / scale
                 worst[names[v]] = max(worst.get(names[v], 0.0), err)
                 assert err < 1e-3, (names[v], (n, h, wd, cin, cout, k, s, act, res_mode), err)
         print({k: f"{v:.1e}" for k, v in worst.items()})
         if math:
-            assert any("splitK" in k for k in worst) and any("win2" in k for k in worst), worst.keys()   # both new kernels really ran
+            assert any("splitK" in k for k in worst) and any("win2" in k for k in worst) and any("win<128,64" in k for k in worst), worst.keys()   # these kernels really ran
     finally:
         lib.yds_set_conv_math(prev)
 
@@ -138,48 +141,3 @@ def test_direct_rgb_kernel_vs_float64():
         want = _conv_ref(x, w, bias, 3, 1, ACT[act], None, 0)
         got = _run(L, direct[0], x, w, bias, 3, 1, ACT[act], None, 0)
         assert float(np.abs(got - want).max()) / float(np.abs(want).max()) < 1e-5
-
-
-def test_window_kernel_cross8_mode_vs_float64():
-    """The opt-in cross8 tier of the window-resident 3x3 kernel (csrc/conv_win.hip, TERMS == 2): hi x hi on the fp16 pipe, both
-    cross terms in fp8 e4m3 with power-of-two block scales.  Stated tolerance: 5e-5 of the output scale per layer (measured
-    ~1.2e-5; the default arithmetic sits at ~5e-7, so the mode must be visibly active), activations spanning three decades,
-    every activation / residual mode, one / several channel groups, ragged tiles; with activations beyond the fp8 range of
-    x / 8 (they clamp, in the cross terms only) 1e-3.  Off again = the default results, bit for bit."""
-    from yolo_deepsort_amd import _lib as L
-    L.init(0)
-    lib = L.load()
-    lib.yds_conv_variant_name.restype = C.c_char_p
-    names = [lib.yds_conv_variant_name(v).decode() for v in range(lib.yds_conv_num_variants())]
-    wins = [names.index(n) for n in ("conv3x3_f16x3_win<256,128,4x2>", "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>")]
-    assert lib.yds_get_conv_math() == 1
-    prev = lib.yds_get_conv_cross8()
-    rng = np.random.RandomState(23)
-    cases = [(2, 19, 19, 64, 128, "leaky", 0), (1, 38, 38, 128, 256, "leaky", 1), (2, 76, 76, 64, 128, "mish", 1), (5, 13, 13, 32, 96, "mish", 0),
-             (7, 8, 4, 256, 256, "relu", 2), (1, 12, 304, 32, 64, "leaky", 1), (1, 19, 19, 512, 1024, "linear", 0)]
-    try:
-        for ci, (n, h, wd, cin, cout, act, res_mode) in enumerate(cases + cases[:2]):
-            outliers = ci >= len(cases)
-            x = (rng.standard_normal((n, h, wd, cin)) * rng.choice([0.03, 1.0, 40.0], (1, 1, 1, cin))).astype(F32)   # per-channel magnitudes over three decades
-            if outliers:
-                x[0, 3:6, 3:6, :4] = [5000.0, -60000.0, 1e-7, 0.0]
-            w = (rng.standard_normal((cout, 9 * cin)) / np.sqrt(9 * cin)).astype(F32)
-            bias = rng.standard_normal(cout).astype(F32)
-            res = rng.standard_normal((n, h, wd, cout)).astype(F32) if res_mode else None
-            want = _conv_ref(x, w, bias, 3, 1, ACT[act], res, res_mode)
-            scale = float(np.abs(want).max())
-            for win in wins:                                   # every tile shape of the window kernel has the mode
-                L.check(lib.yds_set_conv_cross8(0))
-                base = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
-                L.check(lib.yds_set_conv_cross8(1))
-                assert lib.yds_get_conv_cross8() == 1
-                got = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
-                L.check(lib.yds_set_conv_cross8(0))
-                again = _run(L, win, x, w, bias, 3, 1, ACT[act], res, res_mode)
-                e_base, e_x8 = float(np.abs(base - want).max()) / scale, float(np.abs(got - want).max()) / scale
-                assert np.isfinite(got).all()
-                assert e_base < 5e-6 and e_x8 < (1e-3 if outliers else 5e-5), (names[win], (n, h, wd, cin, cout, act, res_mode), e_base, e_x8)
-                assert e_x8 > 2 * e_base, "cross8 mode was not active"
-                assert np.array_equal(base, again)
-    finally:
-        lib.yds_set_conv_cross8(prev)

@@ -1,5 +1,4 @@
 # Socket power and clocks while the dominant window layer runs back to back (run on the GPU box): tools/power_sample.sh
-# arms: default arithmetic on random operands, on operands that never toggle, and the cross8 tier on random operands.
 R=$PWD
 run() {   # $1 label, env assignments follow
   label=$1; shift
@@ -18,4 +17,3 @@ run() {   # $1 label, env assignments follow
 rocm-smi --showmaxpower 2>/dev/null | grep -i -E "max|power" | head -3
 run idle_then_rand YDS_BENCH_DATA=rand
 run zero YDS_BENCH_DATA=zero
-run cross8 YDS_BENCH_DATA=rand YDS_CONV_CROSS8=1

@@ -67,8 +67,6 @@ SIGNATURES = {
     "yds_conv_clock": (_I, [_P, _P, _I]),
     "yds_set_conv_math": (_I, [_I]),
     "yds_get_conv_math": (_I, []),
-    "yds_set_conv_cross8": (_I, [_I]),
-    "yds_get_conv_cross8": (_I, []),
     "yds_conv_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "yds_debug_prof": (_I, [_P, _I]),
     "yds_conv_run": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

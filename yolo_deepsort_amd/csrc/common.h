@@ -89,8 +89,6 @@ struct ConvArgs {
     View x, y;
     const float *w = nullptr, *bias = nullptr;
     const void *w16 = nullptr;   // same weights pre-split for the f16x3 kernel: [cout][kpad/32][32 hi | 32 lo] fp16
-    const void *w16x = nullptr;  // cross8 mode (3x3 stride-1 layers): [cout][kpad/32][32 hi fp16 | 32 lo e4m3 | 32 hi e4m3], see pack_weights_x8
-    int w8_shift = 0;            //   the e4m3 bytes hold w * 2^w8_shift
     View res;              // optional residual (same n,h,w,c as y)
     int ksize = 1, stride = 1, pad = 0, kpad = 0;
     int act = ACT_LINEAR, res_mode = RES_NONE;
@@ -111,16 +109,10 @@ enum ConvMath { MATH_F32 = 0, MATH_F16X3 = 1 };
 int conv_math();                 // process-wide arithmetic mode (env YDS_CONV_MATH=f32|f16x3, default f16x3)
 void set_conv_math(int m);
 void pack_weights_f16x3(const float *w, int cout, int kpad, std::vector<uint16_t> &out);
-// filters of the window kernel's cross8 mode; returns the power-of-two shift of the e4m3 bytes (chosen from max |w|)
-int pack_weights_x8(const float *w, int cout, int kpad, std::vector<uint16_t> &out);
 // process-wide: the window-resident 3x3 kernel computes the two cross terms of the f16x3 product in fp8 e4m3 (conv_win.hip, TERMS == 2;
 // env YDS_CONV_CROSS8=1, default off).  Detector heads move by 2-5e-5 of their maximum; ~1.3x on those layers.
 // mode 1: every network of the process; mode 2: detectors only - the ReID network keeps the default arithmetic, so appearance costs
 // and with them the track ids of crowded scenes stay those of the default mode (1e-5 feature changes flip near-tie assignments).
-bool conv_cross8();
-bool conv_cross8_reid();
-void set_conv_cross8(int mode);
-int get_conv_cross8();
 const char *conv_variant_name(int v);
 double conv_flops(const ConvArgs &a);
 // algorithmic HBM bytes of one conv launch: input read once, weights once, output written once, residual read once

@@ -234,7 +234,6 @@ ConvKernelArgs make_conv_args(const ConvArgs &a) {
     k.act = a.act; k.res_mode = a.res.p ? a.res_mode : RES_NONE;
     k.fmt_x = a.x.fmt; k.fmt_y = a.y.fmt; k.fmt_r = a.res.p ? a.res.fmt : FMT_F32;
     k.terms = a.terms == 1 ? 1 : 3;
-    if (k.terms == 3 && a.w16x && conv_cross8()) { k.w8 = a.w16x; k.w8_shift = a.w8_shift; }   // (only the window kernel looks at it)
     if (a.n_split > 0) {
         if (a.n_split % 4 || a.n_split >= a.y.c || !a.y2.p || a.y2.fmt != a.y.fmt || a.y2.ld % 4 || ((uintptr_t)a.y2.p & 15) || a.res.p)
             fail("conv: bad merged-launch description (n_split %d of %d filters)", a.n_split, a.y.c);
@@ -281,19 +280,6 @@ int conv_math() {
     return g_math;
 }
 void set_conv_math(int m) { g_math = m == MATH_F32 ? MATH_F32 : MATH_F16X3; }
-static int g_cross8 = -1;
-static int cross8_mode() {
-    if (g_cross8 < 0) {
-        const char *e = getenv("YDS_CONV_CROSS8");
-        const int v = e ? atoi(e) : 0;
-        g_cross8 = v == 1 || v == 2 ? v : 0;
-    }
-    return g_cross8;
-}
-bool conv_cross8() { return cross8_mode() != 0; }
-bool conv_cross8_reid() { return cross8_mode() == 1; }
-void set_conv_cross8(int mode) { g_cross8 = mode == 1 || mode == 2 ? mode : 0; }
-int get_conv_cross8() { return cross8_mode(); }
 
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
     ConvKernelArgs k = make_conv_args(a);
@@ -369,7 +355,7 @@ static std::string tune_key(const ConvArgs &a) {
         while (p2 * 2 <= n) p2 *= 2;
         n = n >= p2 + p2 / 2 ? p2 + p2 / 2 : p2;
     }
-    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d_sp%d", conv_math() + (a.terms == 1 ? 10 : 0) + (a.terms != 1 && a.w16x && conv_cross8() ? 20 : 0), n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
+    snprintf(buf, sizeof buf, "m%d_n%d_h%d_w%d_c%d_ld%d_o%d_ho%d_wo%d_k%d_s%d_a%d_r%d_fx%d_fy%d_sp%d", conv_math() + (a.terms == 1 ? 10 : 0), n, a.x.h, a.x.w, a.x.c, a.x.ld, a.y.c,
              a.y.h, a.y.w, a.ksize, a.stride, a.act, a.res.p ? a.res_mode : 0, a.x.fmt, a.y.fmt, a.n_split);
     return buf;
 }
@@ -383,6 +369,7 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
         if (f16v && f16_variant_is_splitk(v - kF32Variants) && !conv_splitk_applicable(make_conv_args(a), v - kF32Variants)) return conv_autotune_measured(a, s, best_us);
         if (v == kDirectVariant && !conv_direct_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (f16v && f16_variant_is_win(v - kF32Variants) && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
+        if (f16v && v - kF32Variants == 10 && (a.terms == 1 || !conv_win16_small_applicable(make_conv_args(a)))) return conv_autotune_measured(a, s, best_us);
         if (f16v && f16_variant_is_win2(v - kF32Variants) && !conv_win2_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (!(presplit && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
     }
@@ -419,6 +406,7 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
         if (f16v && f16_variant_is_win2(fv) && (!conv_win2_applicable(make_conv_args(a)) || a.y.c < 128)) continue;
         if (f16v && f16_variant_is_win(fv) && !conv_win_applicable(make_conv_args(a))) continue;
         if (f16v && f16_variant_is_win(fv) && fv > 8 && a.y.c > 64) continue;          // 64-wide window tiles are for 64-filter layers
+        if (f16v && fv == 10 && (a.terms == 1 || !conv_win16_small_applicable(make_conv_args(a)))) continue;   // the 128x64 tile exists in the default arithmetic only
         cand.push_back(v);
     }
     constexpr int ROUNDS = 2, REPS = 6;

@@ -30,8 +30,6 @@ struct ConvKernelArgs {
     int act, res_mode;
     int fmt_x, fmt_y, fmt_r;              // TensorFmt of input, output and residual views
     int terms;                            // 3: f16x3, 1: hi halves only (half mode; LDS-DMA and window kernels)
-    const void *w8 = nullptr;             // window kernel, cross8 mode: filters as [32 wh fp16 | 32 wl8 | 32 wh8] per K chunk (else null)
-    int w8_shift = 0;                     //   wl8 / wh8 = e4m3(w * 2^w8_shift)
     int ksplit = 1;                       // LDS-DMA kernel: K ranges (grid.y); > 1 writes raw partial sums into slab blockIdx.y of y
     // two convolutions of the same input in one launch (CSP split, darknet.cpp): filters [n_split, Cout) write to y2
     float *y2 = nullptr;
@@ -306,12 +304,13 @@ bool conv_win2_applicable(const ConvKernelArgs &k);
 void launch_conv_win2(ConvKernelArgs k, hipStream_t s);
 // window-resident 3x3 stride-1 kernel (conv_win.hip)
 bool conv_win_applicable(const ConvKernelArgs &k);
-void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s);   // shape 0: 256x128 (4x2 waves), 1: 256x64 (8x1), 2: 256x64 (4x2)
+void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s);   // shape 0: 256x128 (4x2 waves), 1: 256x64 (8x1), 2: 128x64 (4x1, two workgroups per CU; default arithmetic only)
 const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
 // sampled (shader cycles, 100 MHz ticks) accumulated inside the window kernels since the last reset
 void conv_win_clock(unsigned long long *cycles_ticks, bool reset);
 void conv_win16_clock(unsigned long long *cycles_ticks, bool reset);
+bool conv_win16_small_applicable(const ConvKernelArgs &k);           // shape 2 below
 void launch_conv_win16(ConvKernelArgs k, int shape, hipStream_t s);  // the f16x3 (default arithmetic) form on v_mfma_f32_16x16x32_f16 (conv_win16.hip)
 void conv_win2_clock(unsigned long long *cycles_ticks, bool reset);
 void conv_win2_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING2 builds: wait, barrier, body, prologue, epilogue, total cycles, steps, waves

@@ -654,7 +654,7 @@ const char *conv_f16x3_variant_name(int v) {
     static const char *names[kF16Variants] = {"conv_igemm_f16x3<128,128>", "conv_igemm_f16x3<64,128>", "conv_igemm_f16x3<128,64>",
                                               "conv_igemm_f16x3<64,64>", "conv_igemm_f16x3_dma<128,128,2x2,2>", "conv_igemm_f16x3_dma<256,128,4x2,3>",
                                               "conv_igemm_f16x3_dma<128,256,2x4,3>", "conv_igemm_f16x3_dma<128,128,2x2,3>", "conv3x3_f16x3_win<256,128,4x2>",
-                                              "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<256,64,4x2>",
+                                              "conv3x3_f16x3_win<256,64,8x1>", "conv3x3_f16x3_win<128,64,4x1>",
                                               "conv_igemm_f16x3_dma<128,64,2x2,2>", "conv_igemm_f16x3_dma<64,128,2x2,2>", "conv3x3_f16x3_win2<128,128,2x2>",
                                               "conv_igemm_f16x3_dma<64,128,2x2,2>+splitK", "conv_igemm_f16x3_dma<128,128,2x2,2>+splitK"};
     return v >= 0 && v < kF16Variants ? names[v] : "?";
@@ -699,44 +699,6 @@ void pack_weights_f16x3(const float *w, int cout, int kpad, std::vector<uint16_t
             out[base + (k & 31)] = hb;
             out[base + 32 + (k & 31)] = lb;
         }
-}
-
-// e4m3 (OCP fn: 3 mantissa bits, bias 7, no infinities, 0x7f = NaN), round to nearest even, saturating at +-448
-static uint8_t to_e4m3(float x) {
-    const uint8_t sign = x < 0.f ? 0x80 : 0;
-    const float a = fabsf(x);
-    if (!(a < 448.f)) return sign | 0x7e;
-    int ex;
-    (void)frexpf(a, &ex);
-    ex = ex - 1 < -6 ? -6 : ex - 1;                              // exponent of the rounding step (subnormals share 2^-6)
-    const float step = ldexpf(1.f, ex - 3), r = nearbyintf(a / step) * step;
-    if (r == 0.f) return sign;
-    int e2;
-    const float fr = frexpf(r, &e2);
-    e2 -= 1;
-    if (e2 < -6) return sign | (uint8_t)lrintf(r * 512.f);       // subnormal: multiples of 2^-9
-    return sign | (uint8_t)(((e2 + 7) << 3) | (int)lrintf((fr * 2.f - 1.f) * 8.f));
-}
-
-int pack_weights_x8(const float *w, int cout, int kpad, std::vector<uint16_t> &out) {
-    float wmax = 0.f;
-    for (size_t i = 0; i < (size_t)cout * kpad; ++i) wmax = fmaxf(wmax, fabsf(w[i]));
-    int ex = 0;
-    if (wmax > 0.f) (void)frexpf(wmax, &ex);                    // wmax in [2^(ex-1), 2^ex)
-    const int shift = std::max(-100, std::min(100, 8 - ex));     // the largest |w| lands in [128, 256); lo halves are never larger than their hi
-    out.assign((size_t)cout * kpad * 2, 0);
-    uint8_t *bytes = reinterpret_cast<uint8_t *>(out.data());
-    for (int o = 0; o < cout; ++o)
-        for (int k = 0; k < kpad; ++k) {
-            const float x = w[(size_t)o * kpad + k];
-            if (!(fabsf(x) < 65504.f)) fail("conv: weight %g does not fit the fp16 split (|w| must be < 65504)", (double)x);
-            const _Float16 h = (_Float16)x, l = (_Float16)((x - (float)h) * LO_SCALE);
-            const size_t chunk = ((size_t)o * (kpad / 32) + k / 32) * 128;   // byte offset of the K chunk's 128-byte row
-            memcpy(bytes + chunk + (k & 31) * 2, &h, 2);
-            bytes[chunk + 64 + (k & 31)] = to_e4m3(ldexpf((float)l, shift));
-            bytes[chunk + 96 + (k & 31)] = to_e4m3(ldexpf((float)h, shift));
-        }
-    return shift;
 }
 
 }  // namespace yds

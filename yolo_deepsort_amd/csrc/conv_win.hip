@@ -19,23 +19,6 @@
 
 namespace yds {
 
-// TERMS == 2 ("cross8", opt in: yds_set_conv_cross8 / YDS_CONV_CROSS8=1): the hi x hi term stays on the fp16 pipe, the two cross
-// terms hi x lo + lo x hi of a whole 32-channel group go through ONE v_mfma_scale_f32_32x32x64_f8f6f4 in fp8 e4m3:
-//     A bytes [hi8 (32 ch) | lo8 (32 ch)]  x  B bytes [wl8 ; wh8]      lanes 0-31 carry K block 0 (hi8 . wl8), lanes 32-63 block 1 (lo8 . wh8)
-// 2 + 2 + 1 matrix instructions (128 pipe cycles) per 32 channels and accumulator tile instead of 6 (192), and less energy per
-// multiply-accumulate, which is what bounds this kernel (profiles/r03_power_and_clock.txt; tools/probes/fp8_cross_probe.hip: x1.67
-// on the bare pipe under the power limit).  The cross terms are 2^-11 of the product, so their e4m3 rounding (2^-4) costs ~2^-15
-// relative per product: 2-5e-5 of the tensor maximum at the detector heads (tools/fp8_cross_numerics.py), against 2e-6 for f16x3
-// and 1e-3 for half mode.  The tensors in HBM keep the H16 format: the window rows are converted IN LDS, in place, once per
-// channel group (the 64 bytes of lo halves become [32 hi8 | 32 lo8], hi8 = e4m3(hi * 2^X8_SHIFT), same for lo; values beyond
-// +-448 clamp), and the filters come pre-converted ([32 wh fp16 | 32 wl8 | 32 wh8] per K chunk, scaled by 2^w8_shift per layer).
-// The power-of-two scales go into the instruction's E8M0 block-scale operands.
-constexpr int X8_SHIFT = 5;                    // hi8 = e4m3(x / 8): clamps at |x| = 3584 (those values keep half-mode accuracy), full 4-bit precision from
-                                               // |x| = 1/8, subnormal step 2^-6 below (absolute cross-term error there still under that of |x| ~ 1)
-typedef int i8v __attribute__((ext_vector_type(8)));
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-typedef short s2v __attribute__((ext_vector_type(2)));
-
 // Sustained shader clock INSIDE the kernel: one workgroup in 32 samples the shader-cycle counter (s_memtime) and the constant
 // 100 MHz counter (s_memrealtime) at its start and end; cycles / ticks is the clock the chip really ran at while every CU
 // was busy with this kernel (it is power limited: ~1.55 GHz, not the 2.4 GHz the MFMA peak is quoted at).
@@ -49,8 +32,10 @@ constexpr int APW = 7;                         // window DMA instructions per wa
 constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 
 // BN x (WM x WN waves): 128 x (4x2) = 64x64 accumulator tiles per wave; 64 x (8x1) / 64 x (4x2) for 64-filter layers
-// TERMS: 3 = f16x3; 1 = half mode (hi halves of both operands only: no lo fragment reads, one MFMA per product block -
-// compile-time pruning of the same pinned slot plan); 2 = fp16 hi x hi + fp8 cross terms (own step: step8 below);
+// This file holds the HALF-MODE tiers of the window kernel (Darknet.half()); the default f16x3 arithmetic runs conv_win16.hip.
+// TERMS: 1 = half mode (hi halves of both operands only: no lo fragment reads, one MFMA per product block - compile-time
+// pruning of the three-term slot plan; a round-3 tier that computed the cross terms in fp8, TERMS = 2, was removed in round 4:
+// with the default kernel on v_mfma_f32_16x16x32_f16 it was no longer faster - 1487 against 1508 frames/s);
 // 4 = half mode with 64 channels per K step: the LDS rows (window and filter stages alike) are GATHERED by the DMA from the hi halves
 // of two consecutive 32-channel groups (a DMA lane's global address is free), [hi of group 2q | hi of group 2q+1], so the "lo" fragment
 // slots hold the second group's hi values and the step does A_hi x B_hi + A_lo x B_lo - the same DMA instructions, fragment reads and
@@ -59,7 +44,7 @@ constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 template <int BN, int WM, int WN, int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows, int nbuf) {
     static_assert(WM * WN == NW, "eight waves");
-    static_assert(TERMS == 1 || TERMS == 2 || TERMS == 4, "the default arithmetic (three fp16 terms) is conv_win16.hip's kernel");
+    static_assert(TERMS == 1 || TERMS == 4, "the default arithmetic (three fp16 terms) is conv_win16.hip's kernel");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int B_STAGE = BN * ROW;
     constexpr int B_INST = BN / (8 * NW);      // filter DMA instructions per wave per stage (8 rows each)
@@ -97,7 +82,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         const int row = (b * NW + wave) * 8 + drow;
         w_off16[b] = (unsigned)min(n0 + row, p.Cout - 1) * (unsigned)(p.Kpad / 4) + (unsigned)gchunk(dpos ^ ((row >> 1) & 7));
     }
-    const char *x_bytes = reinterpret_cast<const char *>(p.x), *w_bytes = reinterpret_cast<const char *>(TERMS == 2 ? p.w8 : (const void *)p.w);
+    const char *x_bytes = reinterpret_cast<const char *>(p.x), *w_bytes = reinterpret_cast<const char *>(p.w);
     auto a_piece = [&](int g, int k) {                           // window of channel group g -> buffer g & 1
         const int pc = min(k * NW + wave, npieces - 1);        // surplus instructions repeat the last piece (same data, same place)
         const int j = pc * 8 + drow;
@@ -239,113 +224,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         }
     };
 
-    // ---- TERMS == 2: fp16 hi x hi + fp8 cross terms ----
-    // One K step = tap TAP of channel group g:
-    //   substep 0   8 fp16 MFMAs (both k16 blocks) on fh (read during the previous step)   slots: this step's fp8 fragments -> xa / xb
-    //   mid         s_waitcnt vmcnt(0) + s_barrier (as above)
-    //   substep 1   4 fp8 MFMAs (K = 64 each, 64 pipe cycles)   slots: window piece of group g+1, filter pieces of step t+2, the
-    //               fp16 fragments of step t+1 -> fh
-    //   after step 7 of a group: the window of group g+1 (landed for every wave since this step's barrier) is converted in place
-    //   by its row's thread; step 8's barrier publishes it before the first fp8 fragment of the new group is read.
-    h8 fh[2 * (TM + TN)];                                        // [A0 k0, A0 k1, A1 k0, A1 k1, B0 k0, B0 k1, B1 k0, B1 k1]
-    i8v xa[TM], xb[TN];
-    auto hi_read = [&](const char *bst, int f) {
-        const int which = f / 2, s = f & 1;
-        if (which < TM) fh[f] = *reinterpret_cast<const h8 *>(smem + a_addr[which] + (((2 * s + kb) ^ a_sw[which]) << 4));
-        else fh[f] = *reinterpret_cast<const h8 *>(bst + b_frag + (which - TM) * 32 * ROW + bpos_hi[s]);
-    };
-    auto x_read = [&](const char *bst, int f) {                  // 16-byte half f & 1 of fp8 fragment f / 2 (A0, A1, B0, B1)
-        const int which = f / 2, half = f & 1, c = 4 + 2 * kb + half;
-        int4 v;
-        if (which < TM) v = *reinterpret_cast<const int4 *>(smem + a_addr[which] + ((c ^ a_sw[which]) << 4));
-        else v = *reinterpret_cast<const int4 *>(bst + b_frag + (which - TM) * 32 * ROW + ((c ^ swz) << 4));
-        if (which < TM) { xa[which][4 * half] = v.x; xa[which][4 * half + 1] = v.y; xa[which][4 * half + 2] = v.z; xa[which][4 * half + 3] = v.w; }
-        else { xb[which - TM][4 * half] = v.x; xb[which - TM][4 * half + 1] = v.y; xb[which - TM][4 * half + 2] = v.z; xb[which - TM][4 * half + 3] = v.w; }
-    };
-    auto convert_window = [&](int buf) {                         // lo halves of every window row -> [hi8 | lo8], in place
-        const float inv = 1.f / (float)(1 << X8_SHIFT);          // (the conversion divides by its scale operand)
-        const _Float16 lim = (_Float16)(448.f / (float)(1 << X8_SHIFT));
-        const h2v hi_lim = {lim, lim}, lo_lim = {-lim, -lim};
-        for (int j = tid; j < wrows; j += NT) {
-            char *row = smem + buf * WB + j * ROW;
-            const int sw = (j >> 1) & 7;
-            h8 v[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = *reinterpret_cast<const h8 *>(row + ((c ^ sw) << 4));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {                        // output chunk 4 + q <- 16 values of v[2q], v[2q+1]
-                int o[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const h8 &src = v[2 * q + d / 2];
-                    const int e = (d & 1) * 4;
-                    h2v a = {src[e], src[e + 1]}, b = {src[e + 2], src[e + 3]};
-                    a = __builtin_elementwise_max(__builtin_elementwise_min(a, hi_lim), lo_lim);
-                    b = __builtin_elementwise_max(__builtin_elementwise_min(b, hi_lim), lo_lim);
-                    s2v r = {0, 0};
-                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, a, inv, false);
-                    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, b, inv, true);
-                    o[d] = (int)(unsigned short)r[0] | ((int)(unsigned short)r[1] << 16);
-                }
-                *reinterpret_cast<int4 *>(row + (((4 + q) ^ sw) << 4)) = make_int4(o[0], o[1], o[2], o[3]);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    const int scale_a = 127 - X8_SHIFT - 11, scale_b = 127 - p.w8_shift;   // E8M0: A bytes = hi * 2^X8_SHIFT and the cross terms carry 2^-11; B bytes = w * 2^w8_shift
-    auto step8 = [&](int g, auto tap_c, auto last_c) {
-        constexpr int TAP = decltype(tap_c)::value;
-        constexpr bool LAST = decltype(last_c)::value;
-        constexpr int AHEAD = 2;
-        constexpr bool REFILL = !(LAST && TAP + AHEAD > 8);
-        constexpr bool NEXT = !(LAST && TAP == 8);
-        constexpr int TAP1 = (TAP + 1) % 9, TAP2 = (TAP + AHEAD) % 9;
-        // (the window of group g+1 is converted after step 7: every one of its pieces has to be in LDS at that step's barrier)
-        constexpr int NH = 2 * (TM + TN), NX = TM * TN, NHH = 2 * TM * TN;
-        constexpr int OPS = (1 + B_INST + NH + NX - 1) / NX;
-        constexpr int XR = (NH + NHH - 1) / NHH;                // fp8 fragment halves per substep-0 slot (1; 2 for the 64-filter tiles)
-        const int g1 = TAP + 1 >= 9 ? g + 1 : g, g2 = TAP + AHEAD >= 9 ? g + 1 : g;
-        const char *bst = bring + (TAP % NSB) * B_STAGE, *bst1 = bring + ((TAP + 1) % NSB) * B_STAGE;
-#pragma unroll
-        for (int m = 0; m < NHH; ++m) {
-            const int s = m / (TM * TN), ij = m % (TM * TN), i = ij / TN, j = ij % TN;
-            acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh[2 * i + s], fh[2 * (TM + j) + s], acc1[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = m * XR; r < (m + 1) * XR; ++r)
-                if (r < NH) x_read(bst, frag_order(r));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (NEXT) tap_addr(g1, TAP1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < NX; ++m) {
-            const int i = m / TN, j = m % TN;
-            acc1[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xa[i], xb[j], acc1[i][j], 0, 0, 0, scale_a, 0, scale_b);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int o = m * OPS; o < (m + 1) * OPS; ++o) {
-                if (o == 0) { if (!LAST && TAP < APW) a_piece(g + 1, TAP); }
-                else if (o - 1 < B_INST) { if (REFILL) b_piece(g2, TAP2, (TAP + AHEAD) % NSB, o - 1); }
-                else if (o - 1 - B_INST < NH) {
-                    // fp16 fragments of step t+1 in the order its MFMAs need them: k16 block 0 of A0, B0, B1, A1, then block 1
-                    constexpr int order[8] = {0, 2 * TM, 2 * TM + 2, 2, 1, 2 * TM + 1, 2 * TM + 3, 3};
-                    if (NEXT) hi_read(bst1, TM == 2 && TN == 2 ? order[o - 1 - B_INST] : o - 1 - B_INST);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (TAP == 7 && !LAST) convert_window((g + 1) & 1);
-    };
     auto group = [&](int g, auto last_c) {
-        if constexpr (TERMS == 2) {
-            step8(g, std::integral_constant<int, 0>{}, last_c); step8(g, std::integral_constant<int, 1>{}, last_c); step8(g, std::integral_constant<int, 2>{}, last_c);
-            step8(g, std::integral_constant<int, 3>{}, last_c); step8(g, std::integral_constant<int, 4>{}, last_c); step8(g, std::integral_constant<int, 5>{}, last_c);
-            step8(g, std::integral_constant<int, 6>{}, last_c); step8(g, std::integral_constant<int, 7>{}, last_c); step8(g, std::integral_constant<int, 8>{}, last_c);
-            return;
-        } else {
         step(g, std::integral_constant<int, 0>{}, last_c);
         step(g, std::integral_constant<int, 1>{}, last_c);
         step(g, std::integral_constant<int, 2>{}, last_c);
@@ -355,7 +234,6 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         step(g, std::integral_constant<int, 6>{}, last_c);
         step(g, std::integral_constant<int, 7>{}, last_c);
         step(g, std::integral_constant<int, 8>{}, last_c);
-        }
     };
 
     // prologue: window of group 0, filter stages of steps 0 and 1, fragments of step 0 / substep 0
@@ -366,18 +244,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     for (int b = 0; b < B_INST; ++b) b_piece(0, 1, 1, b);
     wait_vmcnt<B_INST>();              // later stages may still be in flight: the mid-step waits cover them
     __syncthreads();                                            // window 0, stage 0 and the zero row are in LDS
-    if (TERMS == 2) {
-        convert_window(0);
-        __syncthreads();
-    }
     tap_addr(0, 0);
-    if (TERMS == 2) {
 #pragma unroll
-        for (int f = 0; f < 2 * (TM + TN); ++f) hi_read(bring, f);
-    } else {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) frag_read(bring, 0, f);
-    }
+    for (int f = 0; f < NF; ++f) frag_read(bring, 0, f);
     __builtin_amdgcn_sched_barrier(0);
 
     for (int g = 0; g + 1 < G; ++g) group(g, std::false_type{});
@@ -437,21 +306,7 @@ bool conv_win_applicable(const ConvKernelArgs &k) {
 
 void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
     if (!conv_win_applicable(k)) fail("conv: the window-resident kernel needs a 3x3 stride-1 layer with a pre-split input and W <= 95 (W <= 318 for 32 input channels)");
-    if (k.terms != 1 && k.w8) {                                  // cross8 mode: fp16 hi x hi + fp8 cross terms
-        if (shape == 0) {
-#define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R, 2>(k, s)
-            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
-#undef YDS_CALL
-        } else if (shape == 1) {
-#define YDS_CALL(A, R) launch_inst_win<64, 8, 1, A, R, 2>(k, s)
-            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
-#undef YDS_CALL
-        } else {
-#define YDS_CALL(A, R) launch_inst_win<64, 4, 2, A, R, 2>(k, s)
-            YDS_DISPATCH_ACT_RES(k, YDS_CALL)
-#undef YDS_CALL
-        }
-    } else if (k.terms == 1 && k.Cin % 64 == 0 && !getenv("YDS_HALF_NARROW")) {   // half mode, 64 channels per step (YDS_HALF_NARROW: tuning aid, the 32-channel form)
+    if (k.terms == 1 && k.Cin % 64 == 0 && !getenv("YDS_HALF_NARROW")) {   // half mode, 64 channels per step (YDS_HALF_NARROW: tuning aid, the 32-channel form)
         if (shape == 0) {
 #define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R, 4>(k, s)
             YDS_DISPATCH_ACT_RES(k, YDS_CALL)

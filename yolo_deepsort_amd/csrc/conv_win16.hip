@@ -34,15 +34,19 @@ __device__ unsigned long long yds_clk_win16[2];        // sampled (shader cycles
 
 namespace {
 
-constexpr int BM = 256, NW = 8, NT = NW * 64;
 constexpr int NSB = 3;                         // filter-stage ring depth
 constexpr int ROW = 128;
-constexpr int APW = 7;                         // window DMA instructions per wave per channel group (8 rows each)
-constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
+constexpr int APW = 7;                         // window DMA instructions per wave per channel group (8 rows each): taps 0-6 of a group carry one
+constexpr int max_wrows(int nw) { return APW * nw * 8; }   // 448 window rows for eight waves, 224 for four
 
-template <int BN, int WM, int WN, int ACT, int RES>
-__global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win16(ConvKernelArgs p, int wrows, int nbuf) {
-    static_assert(WM * WN == NW, "eight waves");
+// BM x BN tile on WM x WN waves.  256 x 128 / 256 x 64 on eight waves: one workgroup per CU (its LDS holds two windows + the
+// ring: 154 KB at W = 76).  128 x 64 on four waves (round 4): 76 KB at W = 32, so TWO workgroups share a CU and one computes
+// while the other runs its prologue / epilogue - the ReID network's 64 -> 64 layers have only 18 K steps per tile, a
+// one-workgroup-per-CU tile spent ~40 % of its time outside the K loop there.
+template <int BM, int BN, int WM, int WN, int ACT, int RES>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv3x3_f16x3_win16(ConvKernelArgs p, int wrows, int nbuf) {
+    constexpr int NW = WM * WN, NT = NW * 64;
+    static_assert(NW == 8 || NW == 4, "eight waves (one workgroup per CU) or four (two)");
     constexpr int RW = BM / WM, CW = BN / WN;                   // rows / filters per wave
     constexpr int TM = RW / 16, TN = CW / 16;                   // 16-row / 16-filter blocks per wave
     constexpr int HM = TM / 2, HN = TN / 2;                     // blocks per half
@@ -254,14 +258,19 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win16(ConvKernelArgs p, i
     }
 }
 
-int window_rows16(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
+int window_rows16(int BM, int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
+size_t win16_smem(int BM, int BN, int W, int Cin) {
+    const int wrows = window_rows16(BM, W), nbuf = Cin == 32 ? 1 : 2;
+    // (the epilogue stages the whole BM x BN tile in the same LDS: narrow images need more than their windows + ring)
+    return std::max((size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW, conv_stage_bytes(BM, BN));
+}
 
-template <int BN, int WM, int WN, int ACT, int RES> void launch_inst_win16(ConvKernelArgs k, hipStream_t s) {
-    const int wrows = window_rows16(k.W), nbuf = k.Cin == 32 ? 1 : 2;
-    // (the epilogue stages the whole 256 x BN tile in the same LDS: narrow images need more than their windows + ring)
-    const size_t smem = std::max((size_t)nbuf * wrows * ROW + (size_t)NSB * BN * ROW + ROW, conv_stage_bytes(BM, BN));
+template <int BM, int BN, int WM, int WN, int ACT, int RES> void launch_inst_win16(ConvKernelArgs k, hipStream_t s) {
+    constexpr int NT = WM * WN * 64;
+    const int wrows = window_rows16(BM, k.W), nbuf = k.Cin == 32 ? 1 : 2;
+    const size_t smem = win16_smem(BM, BN, k.W, k.Cin);
     static size_t attr_set = 0;
-    auto kern = conv3x3_f16x3_win16<BN, WM, WN, ACT, RES>;
+    auto kern = conv3x3_f16x3_win16<BM, BN, WM, WN, ACT, RES>;
     if (smem > attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = smem;
@@ -281,18 +290,29 @@ void conv_win16_clock(unsigned long long *cycles_ticks, bool reset) {
     }
 }
 
-// default arithmetic (f16x3) of the window-resident kernel; applicability is conv_win_applicable's (same LDS plan)
+// the 128 x 64 tile with two workgroups per CU: 64-filter layers whose two windows + ring fit 80 KB and whose window is fetched by
+// at most APW instructions per wave (W <= 43 with several channel groups: 216 window rows)
+bool conv_win16_small_applicable(const ConvKernelArgs &k) {
+    if (!conv_win_applicable(k) || k.Cout > 64) return false;
+    const int wrows = window_rows16(128, k.W), nbuf = k.Cin == 32 ? 1 : 2;
+    if (nbuf == 2 && wrows > max_wrows(4)) return false;
+    return win16_smem(128, 64, k.W, k.Cin) <= 80 * 1024;
+}
+
+// default arithmetic (f16x3) of the window-resident kernel; shapes 0 / 1: applicability is conv_win_applicable's (same LDS plan),
+// shape 2: conv_win16_small_applicable
 void launch_conv_win16(ConvKernelArgs k, int shape, hipStream_t s) {
     if (shape == 0) {
-#define YDS_CALL(A, R) launch_inst_win16<128, 4, 2, A, R>(k, s)
+#define YDS_CALL(A, R) launch_inst_win16<256, 128, 4, 2, A, R>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
     } else if (shape == 1) {
-#define YDS_CALL(A, R) launch_inst_win16<64, 8, 1, A, R>(k, s)
+#define YDS_CALL(A, R) launch_inst_win16<256, 64, 8, 1, A, R>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
     } else {
-#define YDS_CALL(A, R) launch_inst_win16<64, 4, 2, A, R>(k, s)
+        if (!conv_win16_small_applicable(k)) fail("conv: the 128x64 window-resident tile needs a 3x3 stride-1 layer with a pre-split input, at most 64 filters and W <= 43");
+#define YDS_CALL(A, R) launch_inst_win16<128, 64, 4, 1, A, R>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
     }

@@ -413,11 +413,6 @@ void Darknet::load_weights(const void *blob, size_t nbytes, int cutoff) {
             pack_weights_f16x3(packed.data(), co, l.kpad, split);
             l.wt16.upload(split.data(), split.size(), stream);
             YDS_HIP(hipStreamSynchronize(stream));
-            if (k == 3 && l.stride == 1 && cin_p % 32 == 0) {
-                l.w8_shift = pack_weights_x8(packed.data(), co, l.kpad, split);
-                l.wt16x.upload(split.data(), split.size(), stream);
-                YDS_HIP(hipStreamSynchronize(stream));
-            }
         }
         l.bias.upload(bias.data(), bias.size(), stream);
         YDS_HIP(hipStreamSynchronize(stream));
@@ -448,7 +443,7 @@ ConvArgs Darknet::conv_args(int i, int batch) const {
     ConvArgs a;
     a.x = l.src < 0 ? input_view(batch) : view(l.src, batch);
     a.y = view(i, batch);
-    a.w = l.wt.p; a.bias = l.bias.p; a.w16 = l.wt16.p; a.w16x = l.wt16x.p; a.w8_shift = l.w8_shift;
+    a.w = l.wt.p; a.bias = l.bias.p; a.w16 = l.wt16.p;
     a.ksize = l.ksize; a.stride = l.stride; a.pad = l.pad; a.kpad = l.kpad;
     a.act = l.act;
     if (l.fused_res >= 0) { a.res = view(l.fused_res, batch); a.res_mode = RES_AFTER_ACT; }
@@ -463,7 +458,7 @@ ConvArgs Darknet::merged_conv_args(int i, int batch) const {
     a.y2 = b.y;
     a.n_split = a.y.c;
     a.y.c = a.y.c + b.y.c;                                       // (pointer, stride and format stay those of the first output)
-    a.w = l.wt_m.p; a.w16 = l.wt16_m.p; a.w16x = nullptr; a.bias = l.bias_m.p;
+    a.w = l.wt_m.p; a.w16 = l.wt16_m.p; a.bias = l.bias_m.p;
     return a;
 }
 
@@ -471,7 +466,7 @@ void Darknet::autotune(int batch) {
     static const bool off = getenv("YDS_NO_AUTOTUNE") != nullptr;
     for (int i = 0; i < (int)layers.size(); ++i) {
         Layer &l = layers[i];
-        const int mode = conv_math() + (half_mode ? 10 : 0) + (conv_cross8() ? 20 : 0);
+        const int mode = conv_math() + (half_mode ? 10 : 0);
         if (l.type != "convolutional" || !l.loaded || (l.tuned_batch == batch && l.tuned_math == mode)) continue;
         if (l.merged_into >= 0 && layers[l.merged_into].wt_m.p) { l.tuned_batch = batch; l.tuned_math = mode; continue; }   // launched by its partner
         l.variant = off ? -1 : conv_autotune(l.merge_next >= 0 && l.wt_m.p ? merged_conv_args(i, batch) : conv_args(i, batch), stream, nullptr);
@@ -562,9 +557,7 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream) {
                 rec.flops = conv_flops(a) + extra_flops;
                 rec.bytes = conv_bytes(a) + extra_bytes;
                 // bound of the arithmetic the launch really used: f16x3 = three fp16 MFMAs per product block; the window kernel's
-                // cross8 mode = 128 instead of 192 pipe cycles per 32 channels (two fp16 + one fp8 K=64 instruction)
-                const bool cross8 = variant >= kF32Variants + 8 && variant <= kF32Variants + 10 && a.terms != 1 && a.w16x && conv_cross8() && extra_flops == 0.0;
-                const double peak = conv_math() == MATH_F32 ? 157.3e12 : (a.terms == 1 ? 2500e12 : (cross8 ? 2500e12 / 2 : 2500e12 / 3));
+                const double peak = conv_math() == MATH_F32 ? 157.3e12 : (a.terms == 1 ? 2500e12 : 2500e12 / 3);
                 rec.attain_us = std::max(rec.flops / peak, rec.bytes / 6.29e12) * 1e6;
                 conv_pending.push_back(rec);
             }
@@ -899,8 +892,6 @@ const char *yds_conv_variant_name(int v) { return yds::conv_variant_name(v); }
 int yds_conv_num_variants(void) { return yds::kConvVariants; }
 int yds_set_conv_math(int mode) { yds::set_conv_math(mode); return 0; }
 int yds_get_conv_math(void) { return yds::conv_math(); }
-int yds_set_conv_cross8(int mode) { yds::set_conv_cross8(mode); return 0; }
-int yds_get_conv_cross8(void) { return yds::get_conv_cross8(); }
 int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual, int iters, double *avg_us,
                    int *variant) {
     YDS_API_BEGIN
@@ -917,19 +908,13 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
     for (auto &v : hw) v = data_kind == 1 ? 0.f : data_kind == 2 ? 0.03125f : rnd() * 0.05f;
     for (auto &v : hb) v = rnd();
     DevBuf<float> x, wt, b, y((size_t)n * ho * wo * ldy), r((size_t)n * ho * wo * ldy);
-    DevBuf<uint16_t> wt16, wt16x;
-    int w8_shift = 0;
+    DevBuf<uint16_t> wt16;
     x.upload(hx.data(), hx.size()); wt.upload(hw.data(), hw.size()); b.upload(hb.data(), hb.size());
     {
         std::vector<uint16_t> split;
         pack_weights_f16x3(hw.data(), cout, kpad, split);
         wt16.upload(split.data(), split.size());
         YDS_HIP(hipDeviceSynchronize());
-        if (ksize == 3 && stride == 1 && cin % 32 == 0) {
-            w8_shift = pack_weights_x8(hw.data(), cout, kpad, split);
-            wt16x.upload(split.data(), split.size());
-            YDS_HIP(hipDeviceSynchronize());
-        }
     }
     YDS_HIP(hipMemset(r.p, 0, r.n * sizeof(float)));
     ConvArgs a;
@@ -942,7 +927,7 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
         launch_pack_h16(raw.p, a.x, nullptr);
         YDS_HIP(hipDeviceSynchronize());
     }
-    a.w = wt.p; a.w16 = wt16.p; a.w16x = wt16x.p; a.w8_shift = w8_shift; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
+    a.w = wt.p; a.w16 = wt16.p; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
     if (with_residual) { a.res = View{r.p, n, ho, wo, cout, ldy, a.y.fmt}; a.res_mode = RES_AFTER_ACT; }
     if (const char *t = getenv("YDS_BENCH_TERMS")) a.terms = atoi(t) == 1 ? 1 : 3;      // tuning aid: the half-mode kernels on single layers
     hipStream_t st;
@@ -992,18 +977,12 @@ int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize,
     for (int o = 0; o < cout; ++o) memcpy(&hw[(size_t)o * kpad], w_okkc + (size_t)o * K, (size_t)K * sizeof(float));
     const size_t npix_in = (size_t)n * h * w, npix_out = (size_t)n * ho * wo;
     DevBuf<float> x, raw, wt, b, y(npix_out * ldy), r, rraw, out(npix_out * cout);
-    DevBuf<uint16_t> wt16, wt16x;
-    int w8_shift = 0;
+    DevBuf<uint16_t> wt16;
     wt.upload(hw.data(), hw.size()); b.upload(bias, cout);
     std::vector<uint16_t> split;
     pack_weights_f16x3(hw.data(), cout, kpad, split);
     wt16.upload(split.data(), split.size());
     YDS_HIP(hipDeviceSynchronize());
-    if (ksize == 3 && stride == 1 && cin % 32 == 0) {
-        w8_shift = pack_weights_x8(hw.data(), cout, kpad, split);
-        wt16x.upload(split.data(), split.size());
-        YDS_HIP(hipDeviceSynchronize());
-    }
     const bool f16 = conv_math() == MATH_F16X3;
     ConvArgs a;
     a.x = View{nullptr, n, h, w, cin, cin, (f16 && cin % 32 == 0) ? FMT_H16 : FMT_F32};
@@ -1011,7 +990,7 @@ int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize,
     raw.upload(x_nhwc, npix_in * cin);
     if (a.x.fmt == FMT_H16) { x.alloc(npix_in * cin); a.x.p = x.p; launch_pack_h16(raw.p, a.x, nullptr); }
     else a.x.p = raw.p;
-    a.w = wt.p; a.w16 = wt16.p; a.w16x = wt16x.p; a.w8_shift = w8_shift; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
+    a.w = wt.p; a.w16 = wt16.p; a.bias = b.p; a.ksize = ksize; a.stride = stride; a.pad = pad; a.kpad = kpad; a.act = act;
     if (res_mode) {
         if (!res_nhwc) fail("conv_run: residual mode %d without a residual tensor", res_mode);
         a.res = View{nullptr, n, ho, wo, cout, cout, a.y.fmt};

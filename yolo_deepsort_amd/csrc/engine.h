@@ -31,8 +31,6 @@ struct Layer {
     bool loaded = false;
     DevBuf<float> wt, bias;
     DevBuf<uint16_t> wt16;                // split-fp16 copy of wt for the f16x3 kernel
-    DevBuf<uint16_t> wt16x;               // 3x3 stride-1 layers: the window kernel's cross8 filters (pack_weights_x8)
-    int w8_shift = 0;
     // CSP split (yolov4: conv 1x1, route -2, conv 1x1 - two convolutions of the same tensor): the first one launches both
     // (merge_next = the second conv, which is skipped: merged_into = the first) from concatenated filters, so the shared
     // input is read from HBM once
@@ -193,8 +191,7 @@ public:
     struct ConvW {
         int cin = 0, cin_file = 0, cout = 0, k = 0, stride = 1, pad = 0, kpad = 0;
         DevBuf<float> wt, bias;
-        DevBuf<uint16_t> wt16, wt16x;
-        int w8_shift = 0;
+        DevBuf<uint16_t> wt16;
     };
     int max_crops;
     std::map<std::string, std::vector<float>> raw;

@@ -85,11 +85,6 @@ void ReidNet::finalize() {
             pack_weights_f16x3(packed.data(), cout, c.kpad, split);
             c.wt16.upload(split.data(), split.size(), stream);
             YDS_HIP(hipStreamSynchronize(stream));
-            if (k == 3 && stride == 1 && c.cin % 32 == 0) {
-                c.w8_shift = pack_weights_x8(packed.data(), cout, c.kpad, split);
-                c.wt16x.upload(split.data(), split.size(), stream);
-                YDS_HIP(hipStreamSynchronize(stream));
-            }
         }
         c.bias.upload(bias.data(), bias.size(), stream);
         YDS_HIP(hipStreamSynchronize(stream));
@@ -150,12 +145,12 @@ void ReidNet::forward(int D) {
     auto run = [&](int ci, const View &x, const View &y, int act, const View *res, int res_mode) {
         const ConvW &c = convs[ci];
         ConvArgs a;
-        a.x = x; a.y = y; a.w = c.wt.p; a.w16 = c.wt16.p; a.w16x = conv_cross8_reid() ? c.wt16x.p : nullptr; a.w8_shift = c.w8_shift; a.bias = c.bias.p;
+        a.x = x; a.y = y; a.w = c.wt.p; a.w16 = c.wt16.p; a.bias = c.bias.p;
         a.ksize = c.k; a.stride = c.stride; a.pad = c.pad; a.kpad = c.kpad; a.act = act;
         if (res) { a.res = *res; a.res_mode = res_mode; }
         // measured tile choice per layer; the crop count varies from call to call, so a measurement is reused
         // while D stays within a factor of two of the D it was taken at
-        if (tuned_math != conv_math() + (conv_cross8_reid() ? 20 : 0)) { tuned.clear(); tuned_math = conv_math() + (conv_cross8_reid() ? 20 : 0); }
+        if (tuned_math != conv_math()) { tuned.clear(); tuned_math = conv_math(); }
         auto it = tuned.find(ci);
         if (it == tuned.end() || D > 2 * it->second.first || 2 * D < it->second.first) {
             int v = getenv("YDS_NO_AUTOTUNE") ? -1 : conv_autotune(a, stream, nullptr);
@@ -171,7 +166,7 @@ void ReidNet::forward(int D) {
         // stem conv + BN + ReLU + MaxPool2d(3, 2, 1) (model.py:52-60) as one kernel; the unfused pair stays as fallback
         const ConvW &c = convs[0];
         ConvArgs a;
-        a.x = x0; a.y = cur; a.w = c.wt.p; a.w16 = c.wt16.p; a.w16x = conv_cross8_reid() ? c.wt16x.p : nullptr; a.w8_shift = c.w8_shift; a.bias = c.bias.p;
+        a.x = x0; a.y = cur; a.w = c.wt.p; a.w16 = c.wt16.p; a.bias = c.bias.p;
         a.ksize = c.k; a.stride = c.stride; a.pad = c.pad; a.kpad = c.kpad; a.act = ACT_RELU;
         if (!getenv("YDS_REID_UNFUSED") && launch_conv_maxpool3s2(a, stream)) {
             conv_flops_last += 2.0 * D * CROP_H * CROP_W * 64 * 9 * 4;

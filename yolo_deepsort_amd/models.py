@@ -226,20 +226,6 @@ class Darknet:
             pass
 
 
-def set_conv_cross8(on=True, reid=True):
-    """Opt-in precision tier between the default arithmetic and ``half()`` (process wide, no reference counterpart): the
-    window-resident 3x3 kernel keeps hi x hi on the fp16 matrix pipe and computes the two cross terms of the split-fp16 product
-    in fp8 e4m3.  Detector heads move by ~1e-5..5e-5 of their maximum (default 2e-6, half 1e-3); the 3x3 layers run ~1.2x faster
-    (csrc/conv_win.hip, TERMS == 2; env YDS_CONV_CROSS8=1|2 = initial value).  ``reid=False`` (mode 2) leaves the ReID network in
-    the default arithmetic: features, appearance costs and so the track ids of crowded scenes stay those of the default mode."""
-    _lib.check(_lib.load().yds_set_conv_cross8((1 if reid else 2) if on else 0))
-
-
-def get_conv_cross8():
-    """0 = off, 1 = detector and ReID network, 2 = detector only."""
-    return int(_lib.load().yds_get_conv_cross8())
-
-
 def _wrap_like(x, arr):
     """Return a torch tensor when the caller passed one, else numpy."""
     if hasattr(x, "detach"):
