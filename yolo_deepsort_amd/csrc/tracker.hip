@@ -13,914 +13,9 @@
 // single-workgroup kernels built from ordered compactions (ballot + prefix), so a frame is a fixed sequence of launches
 // whose sizes are read from device memory: the host synchronises ONCE per frame - or once per batch of frames
 // (step_batch, used by the pipeline) - to fetch the int32 rows.
-#include "engine.h"
-
-#include <algorithm>
-#include <math.h>
-#include <string.h>
+#include "tracker_dev.h"
 
 namespace yds {
-
-constexpr int EMB = 512;
-constexpr float INFTY_COST = 1e5f;
-constexpr float CHI2_2DOF = 5.9915f;
-
-// ------------------------------------------------------------------------------------------ Kalman
-// std weights are fp32 roundings of 1/20 and 1/160 like the reference's tensors (kalman_filter.py:39-52)
-__device__ __constant__ float kStdPos = 1.f / 20, kStdVel = 1.f / 160;
-
-__device__ __forceinline__ void kf_predict_body(float *m, float *P) {
-    const float h = m[3];
-    float q[8];
-    float sp = h * kStdPos, sv = h * kStdVel;
-    q[0] = sp * sp; q[1] = q[0]; q[2] = 1e-2f * 1e-2f; q[3] = q[0];
-    q[4] = sv * sv; q[5] = q[4]; q[6] = 1e-5f * 1e-5f; q[7] = q[4];
-    float A[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) A[i][j] = i < 4 ? P[i * 8 + j] + P[(i + 4) * 8 + j] : P[i * 8 + j];       // F P
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = j < 4 ? A[i][j] + A[i][j + 4] : A[i][j];                                                 // (F P) F^T
-            if (i == j) v += q[i];
-            P[i * 8 + j] = v;
-        }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = m[i] + m[i + 4];
-}
-__global__ void kf_predict_kernel(float *mean, float *cov, const int *slots, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    kf_predict_body(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64);
-}
-
-__device__ __forceinline__ void project4(const float *m, const float *P, float S[4][4]) {
-    float sp = m[3] * kStdPos;
-    float d[4] = {sp * sp, sp * sp, 1e-1f * 1e-1f, sp * sp};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) S[i][j] = P[i * 8 + j] + (i == j ? d[i] : 0.f);
-}
-
-// z: xyah per match; solves S K^T = (P H)^T by LU with partial pivoting, then the K S K^T form
-__device__ __forceinline__ void kf_update_body(float *m, float *P, const float *zt) {
-    float S[4][4], LU[4][4], Kt[4][8];
-    project4(m, P, S);
-    int piv[4] = {0, 1, 2, 3};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) LU[i][j] = S[i][j];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) Kt[i][j] = P[j * 8 + i];                  // (P H)^T
-    for (int k = 0; k < 4; ++k) {
-        int p = k;
-        float best = fabsf(LU[k][k]);
-        for (int r = k + 1; r < 4; ++r)
-            if (fabsf(LU[r][k]) > best) { best = fabsf(LU[r][k]); p = r; }
-        if (p != k) {
-            for (int j = 0; j < 4; ++j) { float tmp = LU[k][j]; LU[k][j] = LU[p][j]; LU[p][j] = tmp; }
-            for (int j = 0; j < 8; ++j) { float tmp = Kt[k][j]; Kt[k][j] = Kt[p][j]; Kt[p][j] = tmp; }
-            int tp = piv[k]; piv[k] = piv[p]; piv[p] = tp;
-        }
-        for (int r = k + 1; r < 4; ++r) {
-            float f = LU[r][k] / LU[k][k];
-            for (int j = k + 1; j < 4; ++j) LU[r][j] -= f * LU[k][j];
-            for (int j = 0; j < 8; ++j) Kt[r][j] -= f * Kt[k][j];
-        }
-    }
-    for (int k = 3; k >= 0; --k) {
-        for (int j = 0; j < 8; ++j) {
-            float v = Kt[k][j];
-            for (int r = k + 1; r < 4; ++r) v -= LU[k][r] * Kt[r][j];
-            Kt[k][j] = v / LU[k][k];
-        }
-    }
-    float innov[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) innov[i] = zt[i] - m[i];
-    float KS[8][4];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            float v = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v += Kt[c][a] * S[c][b];
-            KS[a][b] = v;
-        }
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            float v = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v += KS[a][c] * Kt[c][b];
-            P[a * 8 + b] = P[a * 8 + b] - v;
-        }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v += innov[i] * Kt[i][j];
-        m[j] = m[j] + v;
-    }
-}
-__global__ void kf_update_kernel(float *mean, float *cov, const int *slots, const float *z, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    kf_update_body(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64, z + t * 4);
-}
-
-// new tracks from detections (kalman_filter.py:54-87 + detection.py:41-48)
-__device__ __forceinline__ void kf_initiate_body(float *m, float *P, const float *b) {
-    float w = b[2], h = b[3];
-    float cx = b[0] + w / 2.f, cy = b[1] + h / 2.f, a = w / h;
-    m[0] = cx; m[1] = cy; m[2] = a; m[3] = h; m[4] = m[5] = m[6] = m[7] = 0.f;
-    const float cp = (float)(2 * (1. / 20)), cv = (float)(10 * (1. / 160));
-    float sp = cp * h, sv = cv * h;
-    float d[8] = {sp * sp, sp * sp, 1e-2f * 1e-2f, sp * sp, sv * sv, sv * sv, 1e-5f * 1e-5f, sv * sv};
-    for (int i = 0; i < 64; ++i) P[i] = 0.f;
-    for (int i = 0; i < 8; ++i) P[i * 9] = d[i];
-}
-__global__ void kf_initiate_kernel(float *mean, float *cov, const int *slots, const float *tlwh, const int *det_idx, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    kf_initiate_body(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64, tlwh + (size_t)det_idx[t] * 4);
-}
-
-__device__ __forceinline__ void to_xyah(const float *b, float z[4]) {
-    z[0] = b[0] + b[2] / 2.f; z[1] = b[1] + b[3] / 2.f; z[2] = b[2] / b[3]; z[3] = b[3];
-}
-
-__global__ void tlwh_to_xyah_kernel(const float *tlwh, const int *det_idx, float *z, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    to_xyah(tlwh + (size_t)det_idx[t] * 4, z + t * 4);
-}
-
-// squared Mahalanobis distance on (x, y) only (only_position=True, tracker.py:61-63)
-__device__ __forceinline__ float gate2(const float *m, const float *P, const float *z) {
-    float sp = m[3] * kStdPos;
-    float s00 = P[0] + sp * sp, s01 = P[1], s10 = P[8], s11 = P[9] + sp * sp;
-    float det = s00 * s11 - s01 * s10;
-    float i00 = s11 / det, i01 = -s01 / det, i10 = -s10 / det, i11 = s00 / det;
-    float d0 = z[0] - m[0], d1 = z[1] - m[1];
-    float t0 = d0 * i00 + d1 * i10, t1 = d0 * i01 + d1 * i11;
-    return t0 * d0 + t1 * d1;
-}
-
-__global__ void gating_kernel(const float *mean, const float *cov, const int *slots, int T, const float *xyah, int D, float *out) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T * D) return;
-    int t = idx / D, d = idx - t * D;
-    out[idx] = gate2(mean + (size_t)slots[t] * 8, cov + (size_t)slots[t] * 64, xyah + d * 4);
-}
-
-// squared Mahalanobis distance on all four measurement dimensions (only_position=False, kalman_filter.py:236-254):
-// d S^-1 d^T with S^-1 by Gauss-Jordan on the 4x4 projected covariance (torch.inverse in the reference)
-__device__ __forceinline__ float gate4(const float *m, const float *P, const float *z) {
-    float S[4][4], I[4][4];
-    project4(m, P, S);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) I[i][j] = i == j ? 1.f : 0.f;
-    for (int k = 0; k < 4; ++k) {
-        int p = k;
-        float best = fabsf(S[k][k]);
-        for (int r = k + 1; r < 4; ++r)
-            if (fabsf(S[r][k]) > best) { best = fabsf(S[r][k]); p = r; }
-        if (p != k)
-            for (int j = 0; j < 4; ++j) { float a = S[k][j]; S[k][j] = S[p][j]; S[p][j] = a; float b = I[k][j]; I[k][j] = I[p][j]; I[p][j] = b; }
-        const float inv = 1.f / S[k][k];
-        for (int j = 0; j < 4; ++j) { S[k][j] *= inv; I[k][j] *= inv; }
-        for (int r = 0; r < 4; ++r) {
-            if (r == k) continue;
-            const float f = S[r][k];
-            for (int j = 0; j < 4; ++j) { S[r][j] -= f * S[k][j]; I[r][j] -= f * I[k][j]; }
-        }
-    }
-    float d[4], t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) d[i] = z[i] - m[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = d[0] * I[0][j] + d[1] * I[1][j] + d[2] * I[2][j] + d[3] * I[3][j];
-    return t[0] * d[0] + t[1] * d[1] + t[2] * d[2] + t[3] * d[3];
-}
-__global__ void gating4_kernel(const float *mean, const float *cov, int T, const float *xyah, int D, float *out) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T * D) return;
-    int t = idx / D, d = idx - t * D;
-    out[idx] = gate4(mean + (size_t)t * 8, cov + (size_t)t * 64, xyah + d * 4);
-}
-// KalmanFilter.initiate from (x, y, a, h) rows (kalman_filter.py:54-87) and KalmanFilter.project (:125-158), stand-alone
-__global__ void kf_initiate_xyah_kernel(const float *xyah, float *mean, float *cov, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const float *z = xyah + (size_t)t * 4;
-    const float b[4] = {z[0] - z[2] * z[3] / 2.f, z[1] - z[3] / 2.f, z[2] * z[3], z[3]};
-    kf_initiate_body(mean + (size_t)t * 8, cov + (size_t)t * 64, b);
-    float *m = mean + (size_t)t * 8;
-    m[0] = z[0]; m[1] = z[1]; m[2] = z[2]; m[3] = z[3];        // the measurement itself, not a tlwh round trip
-}
-__global__ void kf_project_kernel(const float *mean, const float *cov, float *mean4, float *cov16, int n) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float S[4][4];
-    project4(mean + (size_t)t * 8, cov + (size_t)t * 64, S);
-    for (int i = 0; i < 4; ++i) {
-        mean4[(size_t)t * 4 + i] = mean[(size_t)t * 8 + i];
-        for (int j = 0; j < 4; ++j) cov16[(size_t)t * 16 + i * 4 + j] = S[i][j];
-    }
-}
-
-// ------------------------------------------------------------------------------------- appearance cost
-// cost[t][d] = min over the gallery rows of track t of 1 - <g/|g|, f/|f|>, then Mahalanobis gate and the
-// min_cost_matching clamp.  Gallery rows are normalised once when they are appended and detections once per frame
-// (normalize_rows_kernel) - the same division the reference repeats on every call.  One workgroup per (track,
-// 16-detection slab): the slab and 16 gallery rows at a time sit in LDS (rows padded by one float: conflict free),
-// thread (r, d) owns one dot product per chunk and keeps a running minimum.
-__global__ void normalize_rows_kernel(const float *src, const int *src_idx, float *dst, int n, int normalise) {
-    // one wave per row: dst[row] = src[idx[row]] / ||src[idx[row]]||  (plain gather when !normalise: euclidean metric)
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= n) return;
-    const float *f = src + (size_t)(src_idx ? src_idx[row] : row) * EMB;
-    float v[EMB / 64], ss = 0.f;
-#pragma unroll
-    for (int k = 0; k < EMB / 64; ++k) { v[k] = f[lane + 64 * k]; ss += v[k] * v[k]; }
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const float nrm = normalise ? sqrtf(ss) : 1.f;
-#pragma unroll
-    for (int k = 0; k < EMB / 64; ++k) dst[(size_t)row * EMB + lane + 64 * k] = v[k] / nrm;
-}
-
-// Track rows are named either directly (slots / n_rows, the stand-alone entry) or through the device-resident track table:
-// row t = track idx[t] of the table (tab_slot / tab_nfeat), t < *count_p (device-side count; surplus blocks return).
-__global__ __launch_bounds__(256) void appearance_cost_kernel(const float *gallery_n, const int *slots, const int *n_rows, int budget,
-                                                             const float *feats_n, int D, const float *mean, const float *cov,
-                                                             const float *tlwh, float max_dist, float flood, int do_gate, int euclid, float *cost,
-                                                             const int *idx, const int *tab_slot, const int *tab_nfeat, const int *count_p) {
-    __shared__ float fs[16][EMB + 1], gs[16][EMB + 1];
-    __shared__ float best[16][17];
-    const int t = blockIdx.x, d0 = blockIdx.y * 16;
-    if (count_p && t >= *count_p) return;
-    const int nd = min(16, D - d0);
-    const int slot = idx ? tab_slot[idx[t]] : slots[t], rows = idx ? tab_nfeat[idx[t]] : n_rows[t];
-    for (int i = threadIdx.x; i < 16 * (EMB / 4); i += blockDim.x) {        // detection slab, float4 coalesced
-        const int d = i / (EMB / 4), k4 = i % (EMB / 4);
-        float4 v = d < nd ? *reinterpret_cast<const float4 *>(feats_n + (size_t)(d0 + d) * EMB + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        fs[d][k4 * 4] = v.x; fs[d][k4 * 4 + 1] = v.y; fs[d][k4 * 4 + 2] = v.z; fs[d][k4 * 4 + 3] = v.w;
-    }
-    const int r = threadIdx.x >> 4, d = threadIdx.x & 15;
-    float run_min = INFINITY;
-    for (int g0 = 0; g0 < rows; g0 += 16) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 16 * (EMB / 4); i += blockDim.x) {
-            const int g = i / (EMB / 4), k4 = i % (EMB / 4);
-            float4 v = g0 + g < rows ? *reinterpret_cast<const float4 *>(gallery_n + ((size_t)slot * budget + g0 + g) * EMB + k4 * 4)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-            gs[g][k4 * 4] = v.x; gs[g][k4 * 4 + 1] = v.y; gs[g][k4 * 4 + 2] = v.z; gs[g][k4 * 4 + 3] = v.w;
-        }
-        __syncthreads();
-        if (g0 + r < rows) {
-            float dot = 0.f;
-            if (euclid) {                                        // _pdist nn_matching.py:4-27: sum (a - b)^2
-#pragma unroll 8
-                for (int k = 0; k < EMB; ++k) { const float df = gs[r][k] - fs[d][k]; dot += df * df; }
-                run_min = fminf(run_min, dot);
-            } else {
-#pragma unroll 8
-                for (int k = 0; k < EMB; ++k) dot += gs[r][k] * fs[d][k];
-                run_min = fminf(run_min, 1.f - dot);
-            }
-        }
-    }
-    best[r][d] = run_min;
-    __syncthreads();
-    if ((int)threadIdx.x < nd) {
-        float c = INFINITY;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c = fminf(c, best[q][threadIdx.x]);
-        if (euclid) c = fmaxf(c, 0.f);                           // torch.clamp(min=0) nn_matching.py:74
-        const int dd = d0 + threadIdx.x;
-        if (do_gate) {
-            float z[4];
-            to_xyah(tlwh + (size_t)dd * 4, z);
-            if (gate2(mean + (size_t)slot * 8, cov + (size_t)slot * 64, z) > CHI2_2DOF) c = INFTY_COST;
-        }
-        if (max_dist > 0.f && c > max_dist) c = flood;            // linear_assignment.py:52
-        cost[(size_t)t * D + dd] = c;
-    }
-}
-
-// ------------------------------------------------------------------------------------------ IOU cost
-// dims_p (optional): device-side {T, D}; cand / tab_slot / tab_tsu (optional): row t = track cand[t] of the track table
-__global__ void iou_cost_kernel(const float *mean, const int *slots, const int *stale, int T, const float *tlwh, const int *det_idx,
-                                int D, float max_dist, float flood, float *cost, const int *dims_p, const int *cand, const int *tab_slot,
-                                const int *tab_tsu) {
-    if (dims_p) { T = dims_p[0]; D = dims_p[1]; }
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= T * D) return;
-    int t = idx / D, d = idx - t * D;
-    const float *m = mean + (size_t)(cand ? tab_slot[cand[t]] : slots[t]) * 8;
-    float bw = m[2] * m[3], bh = m[3];                        // Track.to_tlwh track.py:81-94
-    float bx = m[0] - bw / 2.f, by = m[1] - bh / 2.f;
-    const float *c = tlwh + (size_t)det_idx[d] * 4;
-    float ix0 = fmaxf(bx, c[0]), iy0 = fmaxf(by, c[1]);
-    float ix1 = fminf(bx + bw, c[2] + c[0]), iy1 = fminf(by + bh, c[3] + c[1]);
-    float iw = fmaxf(ix1 - ix0 + 1.f, 0.f), ih = fmaxf(iy1 - iy0 + 1.f, 0.f);      // asymmetric +1, iou_matching.py:36
-    float inter = iw * ih;
-    float v = 1.f - inter / (bw * bh + c[2] * c[3] - inter);
-    if (cand ? tab_tsu[cand[t]] > 1 : (stale && stale[t])) v = INFTY_COST;      // time_since_update > 1, iou_matching.py:86-89
-    if (max_dist > 0.f && v > max_dist) v = flood;
-    cost[idx] = v;
-}
-
-// ------------------------------------------------------------------------------------------ LSAP
-// scipy.optimize.linear_sum_assignment (rectangular_lsap.cpp, Crouse 2016) on ONE workgroup of four wavefronts.  The
-// augmenting-path search is sequential over rows; its column scan is spread over 256 lanes and the sequential tie-break of
-// the scalar scan is reproduced exactly:
-//   index = last unassigned column (in `remaining` order) among the minimum, else the first minimum
-// encoded as a key so that ONE lexicographic (cost, key) reduction per Dijkstra step finds it.  Arithmetic is fp64 in the
-// same order as scipy (minVal + c - u[i] - v[j]).  Tall matrices are solved transposed.  Position `it` of `remaining` is
-// always scanned - and rewritten - by thread it % 256, the winner's column travels with the reduction, and the per-wave
-// partial results are double buffered, so a Dijkstra step costs one barrier.  Solver state lives in LDS (and the cost
-// matrix too when it fits); beyond ~3000 rows/columns it moves to a global scratch buffer - no size limit.
-// dims_p (optional): device-side {nr, nc}.  row_out/col_out: min(nr,nc) pairs sorted by row, *n_out = that count.
-constexpr int LSAP_NT = 256, LSAP_NW = LSAP_NT / 64;
-#ifndef YDS_LSAP_REG
-#define YDS_LSAP_REG 1                      // experiment builds: 0 = LDS-state workgroup form for every size above 64 columns
-#endif
-#ifndef YDS_LSAP_WAVE_COLS
-#define YDS_LSAP_WAVE_COLS 64
-#endif
-constexpr int LSAP_WAVE_COLS = YDS_LSAP_WAVE_COLS;         // problems up to this many columns go to the single-wavefront kernel (below)
-constexpr size_t LSAP_STATE_BYTES = 3 * sizeof(double) + 6 * sizeof(int);      // per row / column
-constexpr size_t LSAP_LDS_MAX = 150 * 1024;
-
-// Cross-lane helpers of the LSAP kernels.  Everything is passed as scalars: with the candidate in a struct handled through
-// references the compiler kept it in scratch memory (a global-memory round trip per use inside a latency-bound loop).
-template <int CTRL> __device__ __forceinline__ int lsap_dpp_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
-template <int CTRL> __device__ __forceinline__ double lsap_dpp_d(double x) {
-    union { double d; int i[2]; } u, w;
-    u.d = x;
-    w.i[0] = lsap_dpp_i<CTRL>(u.i[0]);
-    w.i[1] = lsap_dpp_i<CTRL>(u.i[1]);
-    return w.d;
-}
-__device__ __forceinline__ double lsap_readlane_d(double x, int lane) {
-    union { double d; int i[2]; } u, w;
-    u.d = x;
-    w.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
-    w.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
-    return w.d;
-}
-// (v, key) <- lexicographic minimum with (ov, ok)
-#define LSAP_TAKE_MIN(v, key, ov, ok)                                      \
-    do {                                                                   \
-        const double _ov = (ov);                                           \
-        const int _ok = (ok);                                              \
-        const bool _t = _ov < (v) || (_ov == (v) && _ok < (key));          \
-        (v) = _t ? _ov : (v);                                              \
-        (key) = _t ? _ok : (key);                                          \
-    } while (0)
-// lexicographic (cost, key) minimum over the wavefront, result in every lane (uniform).  Two phases instead of one
-// 96-bit lexicographic butterfly (round 2: ~80 dependent instructions, 1000+ cycles of every Dijkstra step):
-//   1. the minimum VALUE alone: v_min_f64 over four DPP butterflies inside each row of 16 lanes (quad_perm xor 1, xor 2,
-//      row_half_mirror, row_mirror), then the four row results through v_readlane;
-//   2. lanes holding that value keep their key, the others 0x7fffffff; the minimum KEY with v_min_i32 on DPP operands,
-//      rows combined on the scalar ALU.
-// Identical result: (min value, smallest key among the lanes that attain it).  Values are never NaN; +inf marks dead lanes.
-// (__shfl_xor lowers to ds_bpermute_b32 here: dependent LDS-crossbar round trips.)
-__device__ __forceinline__ void lsap_wave_min(double &v, int &key) {
-    double m = v;
-    m = fmin(m, lsap_dpp_d<0xB1>(m));
-    m = fmin(m, lsap_dpp_d<0x4E>(m));
-    m = fmin(m, lsap_dpp_d<0x141>(m));
-    m = fmin(m, lsap_dpp_d<0x140>(m));
-    const double r = fmin(fmin(lsap_readlane_d(m, 0), lsap_readlane_d(m, 16)), fmin(lsap_readlane_d(m, 32), lsap_readlane_d(m, 48)));
-    int k = v == r ? key : 0x7fffffff;
-    k = min(k, lsap_dpp_i<0xB1>(k));
-    k = min(k, lsap_dpp_i<0x4E>(k));
-    k = min(k, lsap_dpp_i<0x141>(k));
-    k = min(k, lsap_dpp_i<0x140>(k));
-    const int rk = min(min(__builtin_amdgcn_readlane(k, 0), __builtin_amdgcn_readlane(k, 16)),
-                       min(__builtin_amdgcn_readlane(k, 32), __builtin_amdgcn_readlane(k, 48)));
-    v = r;
-    key = rk;
-}
-
-// GSTATE: solver state in the global scratch buffer (huge problems) instead of LDS - a compile-time choice, so that the LDS
-// version addresses its state with ds_read / ds_write (a pointer that may be either makes every access a flat_load)
-template <bool GSTATE, bool COST_LDS>
-__device__ __forceinline__ void lsap_wg_solve(const float *cost, int nr0, int nc0, int *row_out, int *col_out, int *n_out, char *state_global) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool transpose = nc0 < nr0;
-    const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
-    extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
-    __shared__ double red_val[2][LSAP_NW];
-    __shared__ int red_key[2][LSAP_NW], red_col[2][LSAP_NW];
-    const int n = max(nr, nc);
-    double *u, *v, *spc;
-    int *path, *col4row, *row4col, *remaining, *SR, *SC;
-    auto carve = [&](char *base) {
-        u = reinterpret_cast<double *>(base); v = u + n; spc = v + n;
-        path = reinterpret_cast<int *>(spc + n); col4row = path + n; row4col = col4row + n; remaining = row4col + n; SR = remaining + n; SC = SR + n;
-    };
-    if (GSTATE) carve(state_global); else carve(lsap_smem);
-    float *cost_lds = reinterpret_cast<float *>(lsap_smem + (GSTATE ? 0 : (size_t)n * LSAP_STATE_BYTES));
-    if (COST_LDS) {
-        for (int i = tid; i < nr0 * nc0; i += LSAP_NT) cost_lds[i] = cost[i];
-    }
-    // (two typed accesses, not one pointer that may be LDS or global: that would be a flat_load in the inner loop)
-    auto C = [&](int i, int j) -> double {
-        const int at = transpose ? j * nc0 + i : i * nc0 + j;
-        return (double)(COST_LDS ? cost_lds[at] : cost[at]);
-    };
-    for (int i = tid; i < nr; i += LSAP_NT) { u[i] = 0.0; col4row[i] = -1; }
-    for (int j = tid; j < nc; j += LSAP_NT) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
-    __syncthreads();
-    int parity = 0;
-    for (int cur = 0; cur < nr; ++cur) {
-        for (int i = tid; i < nr; i += LSAP_NT) SR[i] = 0;
-        for (int j = tid; j < nc; j += LSAP_NT) { SC[j] = 0; spc[j] = INFINITY; remaining[j] = nc - j - 1; }   // position it <-> thread it % 256
-        __syncthreads();
-        double minVal = 0.0;
-        int num_remaining = nc, i = cur, sink = -1;
-        while (sink == -1) {
-            if (tid == 0) SR[i] = 1;
-            const double ui = u[i];
-            // candidate = lexicographic minimum of (shortest path cost, key): among equal costs the LAST unassigned column in
-            // `remaining` order, otherwise the FIRST column: unassigned -> 0x3fffffff - it, assigned -> 0x40000000 + it
-            double cv = INFINITY;
-            int ckey = 0x7fffffff, cj = -1;
-            for (int it = tid; it < num_remaining; it += LSAP_NT) {
-                const int j = remaining[it];
-                const double r = minVal + C(i, j) - ui - v[j];
-                double sv = spc[j];
-                if (r < sv) { path[j] = i; spc[j] = r; sv = r; }
-                const int key = row4col[j] == -1 ? 0x3fffffff - it : 0x40000000 + it;
-                const bool t = sv < cv || (sv == cv && key < ckey);
-                cv = t ? sv : cv; ckey = t ? key : ckey; cj = t ? j : cj;
-            }
-            const int my_key = ckey;
-            lsap_wave_min(cv, ckey);
-            if (my_key == ckey && ckey != 0x7fffffff) red_col[parity][wave] = cj;      // keys are unique: exactly one lane of the wave
-            if (lane == 0) { red_val[parity][wave] = cv; red_key[parity][wave] = ckey; }
-            __syncthreads();
-            int win = 0;
-            cv = red_val[parity][0]; ckey = red_key[parity][0];
-#pragma unroll
-            for (int w = 1; w < LSAP_NW; ++w) {
-                const double ov = red_val[parity][w];
-                const int ok = red_key[parity][w];
-                const bool t = ov < cv || (ov == cv && ok < ckey);
-                cv = t ? ov : cv; ckey = t ? ok : ckey; win = t ? w : win;
-            }
-            const int j = red_col[parity][win];
-            parity ^= 1;
-            minVal = cv;
-            const int index = ckey < 0x40000000 ? 0x3fffffff - ckey : ckey - 0x40000000;
-            const int owner = row4col[j];
-            if (owner == -1) sink = j; else i = owner;
-            // swap-with-last removal, done by the thread that owns position `index` (the only future reader of it)
-            if (tid == (index & (LSAP_NT - 1))) {
-                SC[j] = 1;
-                remaining[index] = remaining[num_remaining - 1];
-            }
-            --num_remaining;
-        }
-        __syncthreads();
-        // dual update
-        for (int r = tid; r < nr; r += LSAP_NT) {
-            if (r == cur) u[r] += minVal;
-            else if (SR[r]) u[r] += minVal - spc[col4row[r]];
-        }
-        for (int j = tid; j < nc; j += LSAP_NT)
-            if (SC[j]) v[j] -= minVal - spc[j];
-        __syncthreads();
-        if (tid == 0) {
-            int j = sink;
-            while (true) {
-                int r = path[j];
-                row4col[j] = r;
-                int t = col4row[r]; col4row[r] = j; j = t;
-                if (r == cur) break;
-            }
-        }
-        __syncthreads();
-    }
-    if (transpose) {
-        if (tid == 0) {
-            int k = 0;
-            for (int r = 0; r < nc; ++r) {          // nc == original row count
-                int who = row4col[r];
-                if (who >= 0) { row_out[k] = r; col_out[k] = who; ++k; }
-            }
-        }
-    } else {
-        for (int r = tid; r < nr; r += LSAP_NT) { row_out[r] = r; col_out[r] = col4row[r]; }
-    }
-    if (tid == 0 && n_out) *n_out = nr;
-}
-
-
-// ---- register-resident workgroup form for 64 < columns <= 256 (the crowd configuration: 200 tracks x 150 detections).
-// Same algorithm, arithmetic and tie-break key as lsap_wg_solve, but position `it` of `remaining` IS thread `it`: the
-// column it holds, its shortest-path cost, column dual, owner row, that row's dual and the path predecessor stay in
-// registers, so the scan of a Dijkstra step is ONE LDS read (the cost entry) instead of five dependent ones.  Per step:
-// scan -> DPP wave minimum -> one 16-byte candidate + the owner's row dual per wave through LDS -> one barrier -> every
-// thread picks the winner among four.  The swap-with-last removal hands the state of the last position to the winner's
-// position through a double-buffered LDS mailbox written BEFORE the barrier (who is last does not depend on the winner).
-// Selected columns leave their registers, so their final path / shortest-path cost (= minVal at selection) go to LDS at
-// that moment for the dual update and the augmentation.  ~2.7x fewer cycles per step than the LDS-state form.
-struct __attribute__((aligned(16))) LsapCand { double v; int key; unsigned colown; };      // column | (owner row + 1) << 16
-struct __attribute__((aligned(16))) LsapMail { double spc, vj, uo; int j, own, pth, pad; };
-constexpr int LSAP_REG_COLS = 256;
-
-template <bool COST_LDS>
-__device__ __forceinline__ void lsap_reg_solve(const float *cost, int nr0, int nc0, int *row_out, int *col_out, int *n_out) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool transpose = nc0 < nr0;
-    const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;      // nr <= nc <= 256
-    extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
-    __shared__ LsapCand cand[2][LSAP_NW];
-    __shared__ double cand_u[2][LSAP_NW];
-    __shared__ LsapMail mail[2];
-    constexpr int N = LSAP_REG_COLS;
-    double *u = reinterpret_cast<double *>(lsap_smem), *v = u + N, *spc_sel = v + N;
-    int *path = reinterpret_cast<int *>(spc_sel + N), *col4row = path + N, *row4col = col4row + N, *SR = row4col + N, *SC = SR + N;
-    float *cost_lds = reinterpret_cast<float *>(SC + N);
-    if (COST_LDS)
-        for (int i = tid; i < nr0 * nc0; i += LSAP_NT) cost_lds[i] = cost[i];
-    auto C = [&](int i, int j) -> double {
-        const int at = transpose ? j * nc0 + i : i * nc0 + j;
-        return (double)(COST_LDS ? cost_lds[at] : cost[at]);
-    };
-    // SR / SC hold the number (cur + 1) of the row iteration that set them: nothing to clear between iterations
-    if (tid < nr) { u[tid] = 0.0; col4row[tid] = -1; SR[tid] = 0; }
-    if (tid < nc) { v[tid] = 0.0; row4col[tid] = -1; path[tid] = -1; SC[tid] = 0; }
-    __syncthreads();
-    int parity = 0;
-    const int it = tid;
-    for (int cur = 0; cur < nr; ++cur) {
-        const int stamp = cur + 1;
-        // position it holds column nc - it - 1 (scipy fills `remaining` in reverse order); everything read here was final
-        // before the barrier that closed the previous iteration, and the scan below only reads the cost matrix
-        int j = nc - it - 1, own = -1, pth = -1;
-        double spc = INFINITY, vj = 0.0, uo = 0.0;
-        if (it < nc) {
-            vj = v[j];
-            own = row4col[j];
-            uo = own >= 0 ? u[own] : 0.0;
-        }
-        const int c4r = tid < nr ? col4row[tid] : -1;                 // this row's column BEFORE the augmentation (dual update)
-        double minVal = 0.0, ui = u[cur];
-        int num_remaining = nc, i = cur, sink = -1;
-        while (sink == -1) {
-            if (tid == 0) SR[i] = stamp;
-            double cv = INFINITY;
-            int ckey = 0x7fffffff;
-            if (it < num_remaining) {
-                const double r = minVal + C(i, j) - ui - vj;
-                if (r < spc) { pth = i; spc = r; }
-                cv = spc;
-                ckey = own == -1 ? 0x3fffffff - it : 0x40000000 + it;
-            }
-            const int my_key = ckey;
-            lsap_wave_min(cv, ckey);
-            if (ckey == 0x7fffffff) {                                  // no live position in this wave
-                if (lane == 0) { cand[parity][wave].v = INFINITY; cand[parity][wave].key = 0x7fffffff; }
-            } else if (my_key == ckey) {                               // keys are unique: exactly one lane of the wave
-                LsapCand c;
-                c.v = cv; c.key = ckey; c.colown = (unsigned)j | ((unsigned)(own + 1) << 16);
-                cand[parity][wave] = c;
-                cand_u[parity][wave] = uo;
-            }
-            if (it == num_remaining - 1) {                             // the state the winner's position inherits
-                LsapMail m;
-                m.spc = spc; m.vj = vj; m.uo = uo; m.j = j; m.own = own; m.pth = pth; m.pad = 0;
-                mail[parity] = m;
-            }
-            __syncthreads();
-            int win = 0;
-            LsapCand best = cand[parity][0];
-#pragma unroll
-            for (int w = 1; w < LSAP_NW; ++w) {
-                const LsapCand o = cand[parity][w];
-                const bool t = o.v < best.v || (o.v == best.v && o.key < best.key);
-                best.v = t ? o.v : best.v; best.key = t ? o.key : best.key; best.colown = t ? o.colown : best.colown; win = t ? w : win;
-            }
-            const int jw = (int)(best.colown & 0xffffu), owner = (int)(best.colown >> 16) - 1;
-            minVal = best.v;
-            const int index = best.key < 0x40000000 ? 0x3fffffff - best.key : best.key - 0x40000000;
-            if (owner == -1) sink = jw;
-            else { i = owner; ui = cand_u[parity][win]; }
-            if (it == index) {
-                // this thread holds the selected column: its path / cost are final (spc == minVal), then swap-with-last
-                path[jw] = pth; spc_sel[jw] = spc; SC[jw] = stamp;
-                if (index != num_remaining - 1) {
-                    const LsapMail m = mail[parity];
-                    spc = m.spc; vj = m.vj; uo = m.uo; j = m.j; own = m.own; pth = m.pth;
-                }
-            }
-            --num_remaining;
-            parity ^= 1;
-        }
-        __syncthreads();
-        // dual update (selected columns: spc_sel; the sink's entry equals minVal) - and, concurrently on thread 0, the
-        // augmentation: the dual update reads the pre-augmentation columns from registers (c4r), so the two do not interfere
-        if (tid < nr) {
-            if (tid == cur) u[tid] += minVal;
-            else if (SR[tid] == stamp) u[tid] += minVal - spc_sel[c4r];
-        }
-        if (tid < nc && SC[tid] == stamp) v[tid] -= minVal - spc_sel[tid];
-        if (tid == 0) {
-            int jj = sink;
-            while (true) {
-                const int r = path[jj];
-                row4col[jj] = r;
-                const int t = col4row[r]; col4row[r] = jj; jj = t;
-                if (r == cur) break;
-            }
-        }
-        __syncthreads();
-    }
-    if (transpose) {
-        if (tid == 0) {
-            int k = 0;
-            for (int r = 0; r < nc; ++r) {          // nc == original row count
-                const int who = row4col[r];
-                if (who >= 0) { row_out[k] = r; col_out[k] = who; ++k; }
-            }
-        }
-    } else if (tid < nr) { row_out[tid] = tid; col_out[tid] = col4row[tid]; }
-    if (tid == 0 && n_out) *n_out = nr;
-}
-constexpr size_t LSAP_REG_STATE = (size_t)LSAP_REG_COLS * (3 * sizeof(double) + 5 * sizeof(int));
-
-// The launch sizes its LDS from host-side upper bounds (inside a batch the live-track count is only bounded by T + sum D);
-// whether the cost matrix is copied into LDS is decided HERE from the actual sizes - a 200 x 150 problem launched under a
-// bound of 2600 x 150 must not fall back to reading its costs from global memory in the Dijkstra step.
-template <bool GSTATE>
-__global__ __launch_bounds__(LSAP_NT) void lsap_kernel(const float *cost, int nr0, int nc0, const int *dims_p, int *row_out, int *col_out,
-                                                       int *n_out, char *state_global, int smem_bytes) {
-    if (dims_p) { nr0 = dims_p[0]; nc0 = dims_p[1]; }
-    if (nr0 <= 0 || nc0 <= 0) {                                  // linear_assignment.py:48-49 early-out
-        if (threadIdx.x == 0 && n_out) *n_out = 0;
-        return;
-    }
-    if (max(nr0, nc0) <= LSAP_WAVE_COLS) return;                 // solved by lsap_wave_kernel (launched in front of this one)
-    if (YDS_LSAP_REG && max(nr0, nc0) <= LSAP_REG_COLS && LSAP_REG_STATE <= (size_t)smem_bytes) {       // register-resident form
-        if (LSAP_REG_STATE + (size_t)nr0 * nc0 * sizeof(float) <= (size_t)smem_bytes) lsap_reg_solve<true>(cost, nr0, nc0, row_out, col_out, n_out);
-        else lsap_reg_solve<false>(cost, nr0, nc0, row_out, col_out, n_out);
-        return;
-    }
-    const size_t state = GSTATE ? 0 : (size_t)max(nr0, nc0) * LSAP_STATE_BYTES;
-    if (state + (size_t)nr0 * nc0 * sizeof(float) <= (size_t)smem_bytes) lsap_wg_solve<GSTATE, true>(cost, nr0, nc0, row_out, col_out, n_out, state_global);
-    else lsap_wg_solve<GSTATE, false>(cost, nr0, nc0, row_out, col_out, n_out, state_global);
-}
-
-// ---- single-wavefront form for problems with at most 256 columns (after the tall->wide transposition): every lane keeps
-// the scan state of up to four `remaining` positions (column, shortest-path cost, column dual, owner row) in REGISTERS, so a
-// Dijkstra step is one LDS cost read per position, the DPP reduction and a register hand-over for the swap-with-last
-// removal - no barrier and no LDS round trip on the critical path (the workgroup form above spends ~1 us per step).
-// Same arithmetic, same tie-break key, same result.
-constexpr int LSAP_WAVE_SLOTS = LSAP_WAVE_COLS / 64;
-constexpr size_t LSAP_WAVE_COST_MAX = 128 * 1024;               // cost matrix copied to LDS when it fits
-
-#ifndef YDS_LSAP_PROF
-#define YDS_LSAP_PROF 0
-#endif
-__device__ unsigned long long yds_lsap_prof[8];
-// SLOTS positions per lane (1: up to 64 columns, 4: up to 256).  A single wavefront issues one instruction every few cycles,
-// so the step is written for instruction count: only (cost, key) travel through the reduction - the key names the position,
-// whose lane then hands out column and owner - and inactive positions are masked with selects instead of branches.
-template <bool COST_LDS, int SLOTS>
-__device__ __forceinline__ void lsap_wave_solve(const float *cost, const float *cost_lds, int nr0, int nc0, char *smem, int *row_out, int *col_out) {
-    const int lane = threadIdx.x;
-    const bool transpose = nc0 < nr0;
-    const int nr = transpose ? nc0 : nr0, nc = transpose ? nr0 : nc0;
-    double *u = reinterpret_cast<double *>(smem), *v = u + LSAP_WAVE_COLS, *spc_rm = v + LSAP_WAVE_COLS;
-    int *path = reinterpret_cast<int *>(spc_rm + LSAP_WAVE_COLS), *col4row = path + LSAP_WAVE_COLS, *row4col = col4row + LSAP_WAVE_COLS,
-        *SR = row4col + LSAP_WAVE_COLS, *SC = SR + LSAP_WAVE_COLS;
-    const int sj = transpose ? nc0 : 1, si = transpose ? 1 : nc0;       // cost(i, j) at i * si + j * sj
-    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
-    for (int j = lane; j < nc; j += 64) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
-    __syncthreads();
-    for (int cur = 0; cur < nr; ++cur) {
-        int jj[SLOTS], ow[SLOTS], cofs[SLOTS];
-        double sp[SLOTS], vv[SLOTS];
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            const int it = lane + 64 * s, j = nc - 1 - it;          // `remaining` starts as nc-1 .. 0
-            const bool in = it < nc;
-            jj[s] = in ? j : 0; cofs[s] = jj[s] * sj; sp[s] = INFINITY;
-            vv[s] = v[jj[s]]; ow[s] = row4col[jj[s]];
-        }
-        for (int i = lane; i < nr; i += 64) SR[i] = 0;
-        for (int j = lane; j < nc; j += 64) SC[j] = 0;
-        __syncthreads();
-        double minVal = 0.0;
-        int num_remaining = nc, i = cur, sink = -1;
-        unsigned long long t_loop = YDS_LSAP_PROF ? __builtin_amdgcn_s_memtime() : 0, n_it = 0;
-        while (sink == -1) {
-            if (YDS_LSAP_PROF) ++n_it;
-            if (lane == 0) SR[i] = 1;
-            const double ui = u[i];
-            const int row_off = i * si;
-            double cv = INFINITY;
-            int ckey = 0x7fffffff;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const int it = lane + 64 * s;
-                const bool active = it < num_remaining;
-                const int at = row_off + cofs[s];
-                const double cij = (double)(COST_LDS ? cost_lds[at] : cost[at]);
-                const double r = minVal + cij - ui - vv[s];            // scipy's order: minVal + cost - u[i] - v[j]
-                if (active && r < sp[s]) { path[jj[s]] = i; sp[s] = r; }
-                const int key = ow[s] == -1 ? 0x3fffffff - it : 0x40000000 + it;
-                LSAP_TAKE_MIN(cv, ckey, active ? sp[s] : (double)INFINITY, active ? key : 0x7fffffff);
-            }
-            lsap_wave_min(cv, ckey);
-            minVal = cv;
-            const int index = ckey < 0x40000000 ? 0x3fffffff - ckey : ckey - 0x40000000;
-            const int is = SLOTS == 1 ? 0 : index >> 6, il = index & 63;
-            // the position's lane hands out its column and owner
-            int j = 0, own = 0;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s)
-                if (s == is) { j = __builtin_amdgcn_readlane(jj[s], il); own = __builtin_amdgcn_readlane(ow[s], il); }
-            if (own == -1) sink = j; else i = own;
-            // swap-with-last removal: position `index` takes over the registers of position num_remaining - 1
-            const int last = __builtin_amdgcn_readfirstlane(num_remaining - 1);
-            const int ls = SLOTS == 1 ? 0 : last >> 6, ll = last & 63;
-            int t_j = 0, t_o = 0, t_c = 0;
-            union { double d; int w[2]; } t_sp, t_vv, a;
-            t_sp.d = 0.0; t_vv.d = 0.0;
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s)
-                if (s == ls) {                                       // uniform
-                    t_j = __builtin_amdgcn_readlane(jj[s], ll);
-                    t_o = __builtin_amdgcn_readlane(ow[s], ll);
-                    t_c = __builtin_amdgcn_readlane(cofs[s], ll);
-                    a.d = sp[s]; t_sp.w[0] = __builtin_amdgcn_readlane(a.w[0], ll); t_sp.w[1] = __builtin_amdgcn_readlane(a.w[1], ll);
-                    a.d = vv[s]; t_vv.w[0] = __builtin_amdgcn_readlane(a.w[0], ll); t_vv.w[1] = __builtin_amdgcn_readlane(a.w[1], ll);
-                }
-            if (lane == il) { SC[j] = 1; spc_rm[j] = minVal; }       // the removed column keeps its shortest-path cost for the dual update
-#pragma unroll
-            for (int s = 0; s < SLOTS; ++s) {
-                const bool here = s == is && lane == il;
-                jj[s] = here ? t_j : jj[s]; ow[s] = here ? t_o : ow[s]; cofs[s] = here ? t_c : cofs[s];
-                sp[s] = here ? t_sp.d : sp[s]; vv[s] = here ? t_vv.d : vv[s];
-            }
-            --num_remaining;
-        }
-        if (YDS_LSAP_PROF && lane == 0) { yds_lsap_prof[0] += __builtin_amdgcn_s_memtime() - t_loop; yds_lsap_prof[1] += n_it; }
-        __syncthreads();
-        for (int r = lane; r < nr; r += 64) {
-            if (r == cur) u[r] += minVal;
-            else if (SR[r]) u[r] += minVal - spc_rm[col4row[r]];
-        }
-        for (int j = lane; j < nc; j += 64)
-            if (SC[j]) v[j] -= minVal - spc_rm[j];
-        __syncthreads();
-        if (lane == 0) {
-            int j = sink;
-            while (true) {
-                int r = path[j];
-                row4col[j] = r;
-                int t = col4row[r]; col4row[r] = j; j = t;
-                if (r == cur) break;
-            }
-        }
-        __syncthreads();
-    }
-    if (transpose) {
-        if (lane == 0) {
-            int k = 0;
-            for (int r = 0; r < nc; ++r) {          // nc == original row count
-                int who = row4col[r];
-                if (who >= 0) { row_out[k] = r; col_out[k] = who; ++k; }
-            }
-        }
-    } else {
-        for (int r = lane; r < nr; r += 64) { row_out[r] = r; col_out[r] = col4row[r]; }
-    }
-}
-
-constexpr size_t LSAP_WAVE_STATE = (size_t)LSAP_WAVE_COLS * (3 * sizeof(double) + 5 * sizeof(int));
-// big = 0: this launch solves problems with <= 256 columns and leaves larger ones to the workgroup kernel (which is launched
-// with skip_small = 1 right behind it): the sizes are only known on the device, the host picks nothing.
-__global__ __launch_bounds__(64) void lsap_wave_kernel(const float *cost, int nr0, int nc0, const int *dims_p, int *row_out, int *col_out, int *n_out,
-                                                      int cost_lds_floats) {
-    if (dims_p) { nr0 = dims_p[0]; nc0 = dims_p[1]; }
-    extern __shared__ __attribute__((aligned(16))) char lsap_smem[];
-    if (nr0 <= 0 || nc0 <= 0) {
-        if (threadIdx.x == 0 && n_out) *n_out = 0;
-        return;
-    }
-    if (max(nr0, nc0) > LSAP_WAVE_COLS) return;                 // the workgroup kernel's case
-    const unsigned long long t_k = YDS_LSAP_PROF ? __builtin_amdgcn_s_memtime() : 0, w_k = YDS_LSAP_PROF ? wall_clock64() : 0;
-    float *cost_lds = reinterpret_cast<float *>(lsap_smem + LSAP_WAVE_STATE);
-    const bool narrow = max(nr0, nc0) <= 64;                     // one position per lane
-    if (nr0 * nc0 <= cost_lds_floats) {
-        for (int i = threadIdx.x; i < nr0 * nc0; i += 64) cost_lds[i] = cost[i];
-        if (narrow) lsap_wave_solve<true, 1>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
-        else lsap_wave_solve<true, LSAP_WAVE_SLOTS>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
-    } else {
-        if (narrow) lsap_wave_solve<false, 1>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
-        else lsap_wave_solve<false, LSAP_WAVE_SLOTS>(cost, cost_lds, nr0, nc0, lsap_smem, row_out, col_out);
-    }
-    if (threadIdx.x == 0 && n_out) *n_out = min(nr0, nc0);
-    if (YDS_LSAP_PROF && threadIdx.x == 0) {
-        yds_lsap_prof[2] += __builtin_amdgcn_s_memtime() - t_k; yds_lsap_prof[3] += wall_clock64() - w_k; yds_lsap_prof[4] += 1;
-    }
-}
-
-// nr_max / nc_max: upper bounds known on the host (they size the LDS / scratch); the real sizes may come from dims_dev
-static void launch_lsap(const float *cost_dev, int nr_max, int nc_max, const int *dims_dev, int *rows_dev, int *cols_dev, int *n_out_dev,
-                        DevBuf<char> &scratch, hipStream_t s) {
-    {
-        static bool wave_attr = false;
-        if (!wave_attr) {
-            YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(LSAP_WAVE_STATE + LSAP_WAVE_COST_MAX)));
-            wave_attr = true;
-        }
-        const size_t want = (size_t)std::min(nr_max, LSAP_WAVE_COLS) * std::min(nc_max, LSAP_WAVE_COLS) * sizeof(float);
-        const size_t cost_lds = std::min(want, LSAP_WAVE_COST_MAX);
-        hipLaunchKernelGGL(lsap_wave_kernel, dim3(1), dim3(64), LSAP_WAVE_STATE + cost_lds, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev,
-                           n_out_dev, (int)(cost_lds / sizeof(float)));
-        YDS_HIP(hipGetLastError());
-        if (std::max(nr_max, nc_max) <= LSAP_WAVE_COLS) return;
-    }
-    const size_t n = (size_t)std::max(std::max(nr_max, nc_max), 1);
-    const size_t state = n * LSAP_STATE_BYTES, cost_bytes = (size_t)nr_max * nc_max * sizeof(float);
-    const bool state_lds = state <= LSAP_LDS_MAX;
-    // LDS: the state of the largest possible problem, plus the cost matrix if the bounds allow it; when they do not, the whole
-    // LDS is requested anyway and the kernel decides from the actual sizes
-    // (the register-resident form for <= 256 columns keeps a fixed 11 KB of state: make room for it and its cost copy too)
-    const size_t reg_want = LSAP_REG_STATE + (size_t)std::min(nr_max, LSAP_REG_COLS) * std::min(nc_max, LSAP_REG_COLS) * sizeof(float);
-    const size_t smem = std::max(state_lds ? std::min(state + cost_bytes, LSAP_LDS_MAX) : std::min(cost_bytes, LSAP_LDS_MAX),
-                                 std::min(reg_want, LSAP_LDS_MAX));
-    if (!state_lds && scratch.n < state) {
-        YDS_HIP(hipStreamSynchronize(s));                        // nothing may still use the old scratch
-        scratch.alloc(state);
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
-        YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(lsap_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
-        attr_set = true;
-    }
-    auto kern = state_lds ? lsap_kernel<false> : lsap_kernel<true>;
-    hipLaunchKernelGGL(kern, dim3(1), dim3(LSAP_NT), smem, s, cost_dev, nr_max, nc_max, dims_dev, rows_dev, cols_dev, n_out_dev,
-                       state_lds ? (char *)nullptr : scratch.p, (int)smem);
-    YDS_HIP(hipGetLastError());
-}
-
-// ------------------------------------------------------------------------------- tracker-side NMS
-// deep_sort/sort/preprocessing.py:6-73 (gate: deep_sort.py:52-57): greedy suppression in float64 over tlwh boxes with
-// the +1 pixel convention; walks `order` (= np.argsort(scores)) from its END, suppresses j when
-// inter(i, j) / area(j) > max_overlap.  pick[] receives the surviving detection indices in pick order.
-__global__ __launch_bounds__(256) void tracker_nms_kernel(const float *tlwh, const int *order, int n, double max_overlap, int *pick, int *n_pick) {
-    extern __shared__ int alive[];                               // alive[k] for position k of `order`
-    __shared__ int cur, count;
-    for (int k = threadIdx.x; k < n; k += blockDim.x) alive[k] = 1;
-    if (threadIdx.x == 0) { cur = n - 1; count = 0; }
-    __syncthreads();
-    while (true) {
-        const int last = cur;
-        if (last < 0) break;
-        const int i = order[last];
-        const double ix1 = tlwh[i * 4], iy1 = tlwh[i * 4 + 1], ix2 = (double)tlwh[i * 4 + 2] + ix1, iy2 = (double)tlwh[i * 4 + 3] + iy1;
-        for (int k = threadIdx.x; k < last; k += blockDim.x) {
-            if (!alive[k]) continue;
-            const int j = order[k];
-            const double x1 = tlwh[j * 4], y1 = tlwh[j * 4 + 1], x2 = (double)tlwh[j * 4 + 2] + x1, y2 = (double)tlwh[j * 4 + 3] + y1;
-            const double area = (x2 - x1 + 1.0) * (y2 - y1 + 1.0);
-            const double w = fmax(0.0, fmin(ix2, x2) - fmax(ix1, x1) + 1.0), h = fmax(0.0, fmin(iy2, y2) - fmax(iy1, y1) + 1.0);
-            if ((w * h) / area > max_overlap) alive[k] = 0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            pick[count++] = i;
-            int k = last - 1;
-            while (k >= 0 && !alive[k]) --k;
-            cur = k;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *n_pick = count;
-}
 
 // ============================================================================================ device-resident tracker
 enum { TENTATIVE = 1, CONFIRMED = 2, DELETED = 3 };
@@ -1623,14 +718,6 @@ int yds_lsap_bench(const float *cost_host, int nr, int nc, int iters, double *av
     float ms = 0;
     YDS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3 / iters;
-    if (YDS_LSAP_PROF) {
-        unsigned long long v[8];
-        YDS_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(yds_lsap_prof), sizeof v));
-        fprintf(stderr, "lsap prof: loop cycles/iter %.0f, iters/launch %.0f, kernel cycles %.0f, wall ticks(100MHz) %.0f -> %.2f GHz\n",
-                (double)v[0] / v[1], (double)v[1] / v[4], (double)v[2] / v[4], (double)v[3] / v[4], (double)v[2] / ((double)v[3] * 10.0));
-        unsigned long long z[8] = {};
-        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_lsap_prof), z, sizeof z));
-    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     YDS_API_END
 }
