@@ -63,6 +63,30 @@ def _bench_shape(config):
         np.testing.assert_allclose(det, ref, rtol=1e-3, atol=1e-3)
 
 
+def test_one_step_of_32_frames_vs_reference():
+    """bench.py's default step since round 4: ONE pass over 32 consecutive frames (batch-32 tile choices, one ReID pass over the crops of
+    32 frames, 32 frames of association behind one synchronisation) against the reference's rows for the same 32 frames."""
+    from yolo_deepsort_amd.workload import Workload
+    g = golden("bench_shape_cfg2")
+    B = 32
+    assert int(g["n_frames"]) == B
+    wl = Workload("cfg2", batch=B)
+    assert wl.order[:B] == list(range(B))
+    outs = wl.step(0, prefetch=False)
+    st = wl.ds.tracker.state()
+    stats = [0, 0]
+    for t, o in enumerate(outs):
+        if bool(g[f"f{t}_none"]):
+            assert o is None, t
+            continue
+        assert o is not None, t
+        _rows_equal(o, g[f"f{t}_out"], stats)
+    assert np.array_equal(st["ids"], g[f"f{B - 1}_ids"]) and np.array_equal(st["state"], g[f"f{B - 1}_state"])
+    if outs[B - 1] is not None:
+        check_int_rows(outs[B - 1], g[f"f{B - 1}_out"], st, [0, 0])
+    assert stats[1] > 2000 and stats[0] / stats[1] < 5e-3, stats
+
+
 def test_cfg4_second_stream_vs_reference():
     """BASELINE configs[3] (cfg4 = yolov4 + DeepSORT, one stream per GPU, stream seed = rank): rank 1's stream (seed 1) for one
     step of 16 frames against the reference's run on the same frames (rank 0's stream is bench_shape_cfg3)."""

@@ -34,7 +34,7 @@ def main(fetch_csv, write_csv):
         write = 1024.0 * sum(wv) / max(len(wv), 1)
         out[k] = {"launches": len(fv), "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                   "hbm_bytes_per_launch": fetch + write}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950), WRITE_SIZE uncalibrated",
+    json.dump({"frames_per_step": int(__import__("os").environ.get("YDS_PROFILE_BATCH", "32")), "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950), WRITE_SIZE uncalibrated",
                "kernels": out}, sys.stdout, indent=1)
 
 
