@@ -172,8 +172,8 @@ def committed_traffic(config, kernel, B, mode=""):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=32, help="frames per step (detector batch).  32 since round 4: the 19x19 / 38x38 layers have 722 / 2888 wave tiles for 1024 SIMDs at 16 frames "
                                                             "(parallelism bound), twice that at 32: conv time per frame -7 %%, end to end +2 %%; 16 = rounds 1-3")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],

@@ -23,7 +23,7 @@ def key_of(name):
     if kind == "conv3x3_f16x3_win2":
         return f"{kind}<128,128,2x2>"
     if kind == "conv3x3_f16x3_win16":       # the default-arithmetic form of the window kernel (16x16x32 MFMA): same tile variant name as bench.py's
-        return f"conv3x3_f16x3_win<256,{args[0]},{args[1]}x{args[2]}>"
+        return f"conv3x3_f16x3_win<{args[0]},{args[1]},{args[2]}x{args[3]}>"       # template <BM, BN, WM, WN, ...>
     if kind == "conv3x3_f16x3_win":
         return f"{kind}<256,{args[0]},{args[1]}x{args[2]}>"
     if kind == "conv_igemm_f32":
