@@ -7,9 +7,11 @@
 //   Activations are NHWC fp32, so for a fixed filter tap (kh,kw) the K-slice of an output pixel is a
 //   contiguous run of input channels: every global load is a 16-byte, channel-contiguous float4.
 //   Weights are pre-packed [Cout][Kpad] with the same K order and BN already folded in.
-//   A workgroup (4 waves, 256 threads) owns a BM x BN output tile; K is walked in steps of 32 through
-//   a two-stage LDS ring (register prefetch of tile t+1 while tile t feeds the MFMAs, one barrier per
-//   step).  LDS rows are padded to 36 floats so that ds_read_b128 fragment reads are conflict free.
+//   A workgroup (4 waves, 256 threads) owns a BM x BN output tile; K is walked in steps of 32 / 16 through
+//   a two-stage LDS ring fed through registers (three register sets: tile t+1 goes to LDS while tile t feeds
+//   the MFMAs, tiles t+2 / t+3 are in flight), one barrier per step, every LDS / global operation of a step
+//   placed in the shadow of one MFMA (round 4: +3.5 % over the unpipelined form, 0.75-0.80 of the fp32 MFMA
+//   peak on the 3x3 layers; the bare pipe sustains 0.99, tools/probes/mfma_f32_probe.hip).  LDS rows are padded to 36 floats so that ds_read_b128 fragment reads are conflict free.
 //   Fragment trick: lane (i, kk) reads 4 consecutive k for its row with one ds_read_b128 and issues 4
 //   MFMAs, MFMA c consuming component c from both operands - the K order inside a step is permuted
 //   identically for A and B, which a dot product does not care about.
@@ -24,9 +26,7 @@
 
 namespace yds {
 
-// ABL (tuning ablations, compile time): 1 = no global loads in the loop, 2 = no LDS stores / barrier, 4 = no
-// fragment reads from LDS in the loop, 8 = no MFMA.  0 in production.
-template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BK == 16 || BK == 32, "K step");
@@ -76,14 +76,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     int kk = cq * 4, kh = 0, kw = 0, kc = kk;
     while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
 
-    // Global -> register staging, two tiles deep: while tile t feeds the MFMAs out of LDS, tile t+1 sits in one
-    // register set (landing or landed) and the loads of tile t+2 are issued into the other.  A K step is
-    // ~4-8k clocks of MFMA time, one L2/MALL round trip under load is of the same order, so one tile of
-    // prefetch distance left the matrix pipe waiting on vmcnt.  Loads are branch free: out-of-image taps read a
-    // safe address and are zeroed when the tile is written to LDS; rows past M / Cout read a clamped row and
-    // only feed accumulators that are never stored.
-    f32x4 a_reg[2][A_ROWS], b_reg[2][B_ROWS];
-    unsigned a_ok[2] = {0u, 0u};
+    // Global -> register staging, THREE tiles deep (round 4): while tile t feeds the MFMAs out of LDS, tile t+1 sits landed in
+    // one register set and goes to LDS during this step, tile t+2 is in flight in the second and the loads of tile t+3 are
+    // issued into the third - two K steps (4-8k clocks of MFMA time) of distance; with two sets the tile that is stored early
+    // in a step had been requested only one step before, which an HBM round trip under load does not always fit.  Loads are
+    // branch free: out-of-image taps read a safe address and are zeroed when the tile is written to LDS; rows past M / Cout
+    // read a clamped row and only feed accumulators that are never stored.
+    f32x4 a_reg[3][A_ROWS], b_reg[3][B_ROWS];
+    unsigned a_ok[3] = {0u, 0u, 0u};
     const float *w_row[B_ROWS];
 #pragma unroll
     for (int i = 0; i < B_ROWS; ++i) w_row[i] = p.w + (size_t)min(n0 + r0 + RPP * i, p.Cout - 1) * p.Kpad;
@@ -102,6 +102,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
         a_ok[S] = okm;
 #pragma unroll
         for (int i = 0; i < B_ROWS; ++i) b_reg[S][i] = *reinterpret_cast<const f32x4 *>(w_row[i] + kk);
+    };
+    // the same tile, one row per call (the K loop issues them in its MFMA slots): begin_rows, then load_row(q) for q < A_ROWS + B_ROWS
+    int row_tap_off = 0;
+    bool row_k_ok = false;
+    auto load_row = [&](auto set_tag, int q) {
+        constexpr int S = decltype(set_tag)::value;
+        if (q < A_ROWS) {
+            const int iy = a_iy[q] + kh, ix = a_ix[q] + kw;
+            const bool ok = row_k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            a_ok[S] |= (ok ? 1u : 0u) << q;
+            a_reg[S][q] = *reinterpret_cast<const f32x4 *>(p.x + (ok ? a_base[q] + row_tap_off : 0));
+        } else {
+            b_reg[S][q - A_ROWS] = *reinterpret_cast<const f32x4 *>(w_row[q - A_ROWS] + kk);
+        }
     };
     auto advance_k = [&]() {
         kk += BK;
@@ -122,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     };
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
+    using Set2 = std::integral_constant<int, 2>;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -134,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     const int nk = (p.K + BK - 1) / BK;              // Kpad is a multiple of 32 >= K, so BK = 16 may stop earlier
     load_tiles(Set0{});
     if (nk > 1) { advance_k(); load_tiles(Set1{}); }
+    if (nk > 2) { advance_k(); load_tiles(Set2{}); }
     store_tiles(Set0{}, 0);
     // Two workgroups share a CU (one wave of each per SIMD).  Left alone they run in lockstep and hit their
     // barrier / LDS-latency gaps together, idling the matrix pipe; delaying every other resident workgroup by
@@ -152,44 +168,94 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
         for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const f32x4 *>(b_lds + buf * BN * LDS_LD + j * 32 * LDS_LD + ks * 8);
     };
     load_frags(0, 0, 0);
-    // one K step; PAR = kt & 1 is compile time so that the register sets are statically indexed
-    auto k_step = [&](auto par_tag, int kt) {
-        constexpr int PAR = decltype(par_tag)::value;
-        using Free = std::integral_constant<int, PAR>;          // set that held tile kt (already in LDS)
-        using Next = std::integral_constant<int, PAR ^ 1>;      // set that holds tile kt+1
-        if (!(ABL & 1) && kt + 2 < nk) { advance_k(); load_tiles(Free{}); }
-#pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            if (!(ABL & 4) && ks + 1 < BK / 8) load_frags(PAR, ks + 1, (ks + 1) & 1);       // next fragments fly under these MFMAs
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (ABL & 8) acc[i][j][c] += af[ks & 1][i][c] * bf[ks & 1][j][c];
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i][c], bf[ks & 1][j][c], acc[i][j], 0, 0, 0);
-        }
-        const bool more = kt + 1 < nk;
-        if (!(ABL & 2)) {
-            if (more) store_tiles(Next{}, PAR ^ 1);
-            __syncthreads();
-        }
-        if (!(ABL & 4) && more) load_frags(PAR ^ 1, 0, 0);
+    // One K step, software pipelined across its barrier (round 4; the fp32 matrix pipe sustains 0.99 of its peak in a bare loop -
+    // tools/probes/mfma_f32_probe.hip - so everything this kernel loses is schedule): PAR = kt & 1 is compile time so that the
+    // register sets are statically indexed.  An MFMA keeps the pipe busy for 64 cycles and the wave issues in order, so every
+    // LDS operation rides in the shadow of one MFMA, order pinned:
+    //   substeps 0 .. NKS-2   MFMAs on fragments read earlier    slots: the next substep's fragments, then the LDS stores of tile
+    //                                                               kt+1 (its registers landed during the previous step) into the
+    //                                                               other buffer - nobody reads that buffer since step kt-1's barrier
+    //   barrier               tile kt+1 is complete in LDS
+    //   substep NKS-1         MFMAs                                slots: substep-0 fragments of tile kt+1, then the global loads
+    //                                                               of tile kt+3 (row addresses + bounds tests in MFMA shadows)
+    // so a step boundary costs no LDS round trip: the next step starts on fragments that are already in registers.
+    constexpr int NKS = BK / 8, NMB = 4 * TM * TN;               // substeps per K step, MFMAs per substep
+    constexpr int NFR = TM + TN, NST = A_ROWS + B_ROWS;          // fragment reads per substep, LDS stores (= global row loads) per K step
+    constexpr int OPS = (NFR + NST + NMB - 1) / NMB;             // memory operations per MFMA slot (1 for the wide tiles)
+    auto frag_one = [&](int buf, int ks, int slot, int f) {        // fragment f of a substep: A tiles first, then B tiles
+        if (f < TM) af[slot][f] = *reinterpret_cast<const f32x4 *>(a_lds + buf * BM * LDS_LD + f * 32 * LDS_LD + ks * 8);
+        else bf[slot][f - TM] = *reinterpret_cast<const f32x4 *>(b_lds + buf * BN * LDS_LD + (f - TM) * 32 * LDS_LD + ks * 8);
     };
-    for (int kt = 0; kt < nk; kt += 2) {
-        k_step(Set0{}, kt);
-        if (kt + 1 < nk) k_step(Set1{}, kt + 1);
+    auto k_step = [&](auto set_tag, auto buf_tag, int kt) {
+        constexpr int SET = decltype(set_tag)::value, PAR = decltype(buf_tag)::value;   // register set of tile kt (kt % 3), its LDS buffer (kt & 1)
+        using Free = std::integral_constant<int, SET>;          // set that held tile kt (already in LDS): takes tile kt+3
+        constexpr int NEXT = (SET + 1) % 3, NBUF = PAR ^ 1;     // set holding tile kt+1, the LDS buffer it goes to
+        const bool more = kt + 1 < nk, fetch = kt + 3 < nk;
+        float *a_next = As + NBUF * BM * LDS_LD, *b_next = Bs + NBUF * BN * LDS_LD;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks == NKS - 1) {
+                if (more) __syncthreads();                      // every wave's part of tile kt+1 is in LDS
+                if (fetch) {                                    // tile kt+3 -> the set tile kt left: its rows ride in this substep's slots
+                    advance_k();
+                    row_tap_off = (kh * p.W + kw) * p.ldx + kc;
+                    row_k_ok = kk < p.K;
+                    a_ok[SET] = 0u;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int m = 0; m < NMB; ++m) {
+                const int c = m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i][c], bf[ks & 1][j][c], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int o = m * OPS; o < (m + 1) * OPS; ++o) {
+                    if (ks + 1 < NKS) {
+                        if (o < NFR) frag_one(PAR, ks + 1, (ks + 1) & 1, o);
+                        else if (ks == 0 && more && o - NFR < NST) {
+                            const int q = o - NFR;
+                            if (q < A_ROWS) {
+                                f32x4 v = a_reg[NEXT][q];
+                                if (!((a_ok[NEXT] >> q) & 1u)) v = f32x4{0, 0, 0, 0};
+                                *reinterpret_cast<f32x4 *>(a_next + (r0 + RPP * q) * LDS_LD + cq * 4) = v;
+                            } else {
+                                *reinterpret_cast<f32x4 *>(b_next + (r0 + RPP * (q - A_ROWS)) * LDS_LD + cq * 4) = b_reg[NEXT][q - A_ROWS];
+                            }
+                        }
+                    } else if (o < NFR) {
+                        if (more) frag_one(NBUF, 0, 0, o);      // (slot 0 was last used by substep NKS-2, issued before the barrier)
+                    } else if (fetch && o - NFR < NST) {
+                        load_row(Free{}, o - NFR);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    // set = kt % 3, buffer = kt & 1: six steps per trip keep both static; the last 0..5 steps fall through a chain of tests
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 6 <= nk; kt += 6) {
+        k_step(Set0{}, B0{}, kt); k_step(Set1{}, B1{}, kt + 1); k_step(Set2{}, B0{}, kt + 2);
+        k_step(Set0{}, B1{}, kt + 3); k_step(Set1{}, B0{}, kt + 4); k_step(Set2{}, B1{}, kt + 5);
     }
+    if (kt < nk) k_step(Set0{}, B0{}, kt);
+    if (kt + 1 < nk) k_step(Set1{}, B1{}, kt + 1);
+    if (kt + 2 < nk) k_step(Set2{}, B0{}, kt + 2);
+    if (kt + 3 < nk) k_step(Set0{}, B1{}, kt + 3);
+    if (kt + 4 < nk) k_step(Set1{}, B0{}, kt + 4);
+    __syncthreads();                                            // the epilogue stages through the same LDS
 
     static_assert((BM / WM) * (BN + 4) <= 2 * (BM + BN) * LDS_LD, "epilogue staging must fit the main-loop LDS");
     conv_epilogue<BM, BN, WM, WN, ACT, RES>(p, acc, smem, m0, n0, tid);
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES, int ABL = 0> static void launch_inst(ConvKernelArgs k, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES> static void launch_inst(ConvKernelArgs k, hipStream_t s) {
     constexpr size_t smem = 2ull * (BM + BN) * (BK + 4) * sizeof(float);
     static bool attr_set = false;
-    auto kern = conv_igemm_f32<BM, BN, WM, WN, BK, ACT, RES, ABL>;
+    auto kern = conv_igemm_f32<BM, BN, WM, WN, BK, ACT, RES>;
     if (!attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
@@ -299,17 +365,6 @@ int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
         k.w = reinterpret_cast<const float *>(a.w16);
         launch_conv_f16x3(k, variant - kF32Variants, s);
         return variant;
-    }
-    static const int abl = getenv("YDS_CONV_ABL") ? atoi(getenv("YDS_CONV_ABL")) : 0;
-    if (abl && variant == 0 && k.act == ACT_LEAKY && k.res_mode == RES_NONE) {
-        switch (abl) {
-            case 1: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 1>(k, s); return 0;
-            case 2: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 2>(k, s); return 0;
-            case 3: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 3>(k, s); return 0;
-            case 7: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 7>(k, s); return 0;
-            case 8: launch_inst<128, 128, 2, 2, 32, ACT_LEAKY, RES_NONE, 8>(k, s); return 0;
-            default: break;
-        }
     }
     switch (variant) {
         case 0: launch_cfg<128, 128, 2, 2, 32>(k, s); break;
