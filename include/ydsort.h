@@ -266,10 +266,6 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
  * *sampled_ms = the workgroup time that was sampled.  The dense-MFMA peaks are quoted at 2.4 GHz; under this load the chip
  * is power limited well below that, which bench.py reports next to the nominal roofline fraction. */
 int yds_conv_clock(double *ghz, double *sampled_ms, int reset);
-/* tuning aid (YDS_TIMING / YDS_TIMING2 experiment builds only): accumulated s_memtime phase counters of the LDS-DMA conv kernel
- * (reset = 0 / 1), of the two-workgroup window kernel (reset = 2 / 3: wait, barrier, body, prologue, epilogue, total, steps, waves) or of
- * the 512-thread window kernel (YDS_TIMING_WIN; reset = 4 / 5: prologue, K loop, epilogue cycles, sampled workgroups) */
-int yds_debug_prof(uint64_t *out8, int reset);
 /* parity-test entry: one convolution through a chosen kernel variant (formats as the planner would pick them for the
  * current conv math).  x NHWC [n,h,w,cin], w [cout][kh][kw][cin] (BN already folded), res NHWC or NULL
  * (res_mode 0 none, 1 after the activation, 2 before it), y NCHW [n,cout,ho,wo]. */

@@ -68,7 +68,6 @@ SIGNATURES = {
     "yds_set_conv_math": (_I, [_I]),
     "yds_get_conv_math": (_I, []),
     "yds_conv_bench": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "yds_debug_prof": (_I, [_P, _I]),
     "yds_conv_run": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "yds_nms": (_I, [_P, _I, _F, _F, _I, _I, _P, _I, _P]),
     "yds_nms_pred": (_I, [_P, _I, _I, _F, _F, _P, _I, _P]),

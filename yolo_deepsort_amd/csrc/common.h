@@ -109,10 +109,6 @@ enum ConvMath { MATH_F32 = 0, MATH_F16X3 = 1 };
 int conv_math();                 // process-wide arithmetic mode (env YDS_CONV_MATH=f32|f16x3, default f16x3)
 void set_conv_math(int m);
 void pack_weights_f16x3(const float *w, int cout, int kpad, std::vector<uint16_t> &out);
-// process-wide: the window-resident 3x3 kernel computes the two cross terms of the f16x3 product in fp8 e4m3 (conv_win.hip, TERMS == 2;
-// env YDS_CONV_CROSS8=1, default off).  Detector heads move by 2-5e-5 of their maximum; ~1.3x on those layers.
-// mode 1: every network of the process; mode 2: detectors only - the ReID network keeps the default arithmetic, so appearance costs
-// and with them the track ids of crowded scenes stay those of the default mode (1e-5 feature changes flip near-tie assignments).
 const char *conv_variant_name(int v);
 double conv_flops(const ConvArgs &a);
 // algorithmic HBM bytes of one conv launch: input read once, weights once, output written once, residual read once

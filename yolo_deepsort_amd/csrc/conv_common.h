@@ -39,10 +39,7 @@ struct ConvKernelArgs {
 };
 
 constexpr int KALIGN = 32;                // weight rows are zero padded to a multiple of this
-#ifndef YDS_STAGGER
-#define YDS_STAGGER 24
-#endif
-constexpr int STAGGER = YDS_STAGGER;     // s_sleep units of 64 clocks
+constexpr int STAGGER = 24;              // s_sleep units of 64 clocks: start offset of every other resident workgroup (staged kernels)
 
 template <int ACT> __device__ __forceinline__ float apply_act(float v) {
     if (ACT == ACT_LEAKY) return v > 0.f ? v : v * 0.1f;
@@ -313,7 +310,5 @@ void conv_win16_clock(unsigned long long *cycles_ticks, bool reset);
 bool conv_win16_small_applicable(const ConvKernelArgs &k);           // shape 2 below
 void launch_conv_win16(ConvKernelArgs k, int shape, hipStream_t s);  // the f16x3 (default arithmetic) form on v_mfma_f32_16x16x32_f16 (conv_win16.hip)
 void conv_win2_clock(unsigned long long *cycles_ticks, bool reset);
-void conv_win2_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING2 builds: wait, barrier, body, prologue, epilogue, total cycles, steps, waves
-void conv_debug_prof(unsigned long long *out, bool reset);   // YDS_TIMING builds: wait / barrier / body / total cycles, steps, waves
 
 }  // namespace yds

@@ -27,25 +27,6 @@ namespace yds {
 
 
 constexpr int ROWB = 144;                 // bytes per LDS row
-#ifndef YDS_PRIO_MODE
-#define YDS_PRIO_MODE 0                   // experiment: static wave priorities to keep co-resident workgroups out of lock-step
-#endif
-__device__ __forceinline__ void set_static_prio() {
-    if (YDS_PRIO_MODE == 1) {             // by hardware wave slot (HW_ID[3:0]): the two waves sharing a SIMD differ
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        if (slot & 1) __builtin_amdgcn_s_setprio(3);
-    } else if (YDS_PRIO_MODE == 2) {      // by dispatch wave of 256 workgroups
-        if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(3);
-    }
-}
-#ifndef YDS_TIMING
-#define YDS_TIMING 0                      // experiment: s_memtime phase accounting in the LDS-DMA kernel (yds_debug_prof)
-#endif
-__device__ unsigned long long yds_prof[8];
-#ifndef YDS_F16_ABL
-#define YDS_F16_ABL 0                     // tools/ ablation builds: 1 no global loads in the K loop, 2 + no LDS stores, 3 no MFMA
-#endif
-
 __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -77,7 +58,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
         m0 = tm * BM;
         n0 = tn * BN;
     }
-    set_static_prio();
     const int cq = tid & 7;          // which 4 of the 32 k (A, fp32) / which 16-byte chunk of the 128-byte weight row
     const int r0 = tid >> 3;         // first staged row; further rows at +32
 
@@ -186,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc1[i][j][e] = 0.f; acc2[i][j][e] = 0.f; }
 
-    const int nk = YDS_F16_ABL == 4 ? 1 : p.Kpad / 32;       // ablation 4: prologue + epilogue only
+    const int nk = p.Kpad / 32;
     load_tiles();
     store_tiles(0);
     if (STAGGER && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(STAGGER / 4);
@@ -198,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more) { advance_k(); if (YDS_F16_ABL != 1 && YDS_F16_ABL != 2) load_tiles(); }
+        if (more) { advance_k(); load_tiles(); }
         const char *a = a_lds + cur * BM * ROWB, *b = b_lds + cur * BN * ROWB;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                      // two MFMA k-steps of 16 per staged tile of 32
@@ -217,13 +197,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (YDS_F16_ABL == 3) { acc1[i][j][0] += (float)ah[i][0] + (float)bl[j][0] + (float)al[i][0] + (float)bh[j][0]; continue; }
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc1[i][j], 0, 0, 0);
                     acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc2[i][j], 0, 0, 0);
                     acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc2[i][j], 0, 0, 0);
                 }
         }
-        if (more && YDS_F16_ABL != 2) store_tiles(cur ^ 1);
+        if (more) store_tiles(cur ^ 1);
         __syncthreads();
     }
     // recombine the two accumulator sets and undo the activation scale
@@ -234,12 +213,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     static_assert(BM * (BN + 4) * 4 <= 2 * (BM + BN) * ROWB, "whole-tile epilogue staging must fit the main-loop LDS");
-    if (YDS_F16_ABL == 5) {                                   // ablation 5: K loop only
-        float t = 0.f;
-        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int e = 0; e < 16; ++e) t += acc1[i][j][e];
-        if (t == 123.456f) p.y[0] = t;
-        return;
-    }
     conv_epilogue<BM, BN, WM, WN, ACT, RES, BM / WM / 32, BN / WN / 32, 256, true>(p, acc1, reinterpret_cast<float *>(smem16), m0, n0, tid);
 }
 
@@ -282,7 +255,6 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         m0 = tm * BM;
         n0 = tn * BN;
     }
-    set_static_prio();
     // DMA lane roles: instruction q of this wave fills rows (q*NW + wave)*8 .. +7; lane -> (row, 16-byte position)
     const int drow = lane >> 3, dpos = lane & 7;
     int a_base[A_INST], a_iy[A_INST], a_ix[A_INST];
@@ -450,20 +422,10 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         if (REFILL) advance_tile();
     };
     int t = 0;
-    unsigned long long c_wait = 0, c_bar = 0, c_body = 0, c_start = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
     for (; t + NS - 1 < nk; ++t) {                             // steady state: NS-2 younger tiles stay in flight
-        unsigned long long t0 = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
         wait_vmcnt<(NS - 2) * IN>();
-        unsigned long long t1 = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
         __builtin_amdgcn_s_barrier();
-        unsigned long long t2 = YDS_TIMING ? __builtin_amdgcn_s_memtime() : 0;
         step(t, std::true_type{});
-        if (YDS_TIMING) { unsigned long long t3 = __builtin_amdgcn_s_memtime(); c_wait += t1 - t0; c_bar += t2 - t1; c_body += t3 - t2; }
-    }
-    if (YDS_TIMING && lane == 0) {
-        unsigned long long t3 = __builtin_amdgcn_s_memtime();
-        atomicAdd(&yds_prof[0], c_wait); atomicAdd(&yds_prof[1], c_bar); atomicAdd(&yds_prof[2], c_body);
-        atomicAdd(&yds_prof[3], t3 - c_start); atomicAdd(&yds_prof[4], (unsigned long long)t); atomicAdd(&yds_prof[5], 1ull);
     }
     for (; t < nk; ++t) {                                       // drain: nothing left to fetch
         const int younger = nk - 1 - t;
@@ -639,14 +601,6 @@ template <int BM, int BN> static void launch_cfg16(const ConvKernelArgs &k, hipS
 #define YDS_CALL(A, R) launch_inst16<BM, BN, A, R, FMT_F32>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
-    }
-}
-
-void conv_debug_prof(unsigned long long *out, bool reset) {
-    YDS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(yds_prof), sizeof(unsigned long long) * 8));
-    if (reset) {
-        unsigned long long z[8] = {};
-        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_prof), z, sizeof(z)));
     }
 }
 

@@ -196,13 +196,7 @@ __global__ __launch_bounds__(256) void conv3x3_rgb_pool(ConvKernelArgs p, int Hp
 // fragments = first operand, in registers; pixel fragments gathered from a split RGB tile in LDS as in conv_stem2.hip; a
 // lane ends up with 4 consecutive channels of one pixel), written to LDS as fp32 after bias + activation (-inf where the
 // position lies outside the image: the pool pads with -inf), and pooled from there.
-#ifndef YDS_MP_TH
-#define YDS_MP_TH 3
-#endif
-#ifndef YDS_MP_OCC
-#define YDS_MP_OCC 2
-#endif
-constexpr int MP_TH = YDS_MP_TH, MP_TW = 16;                        // pooled patch (YDS_MP_TH / YDS_MP_OCC: tuning - rows per patch, workgroups per CU)
+constexpr int MP_TH = 3, MP_OCC = 2, MP_TW = 16;                        // pooled patch: rows per patch, workgroups per CU, columns
 constexpr int MP_CR = 2 * MP_TH + 1, MP_CC = 2 * MP_TW + 1;         // conv region 9 x 33
 constexpr int MP_IR = MP_CR + 2, MP_IC = MP_CC + 2;                 // input tile 11 x 35
 constexpr int MP_CONV = MP_CR * MP_CC;                              // 297
@@ -210,7 +204,7 @@ constexpr int MP_LD = 68;                                           // floats pe
 constexpr int MP_NT = 512;
 
 template <int ACT>
-__global__ __launch_bounds__(MP_NT, YDS_MP_OCC) void conv3x3_rgb_pool_mfma(ConvKernelArgs p, int Hp, int Wp, int tiles_y, int tiles_x, int n_tiles) {
+__global__ __launch_bounds__(MP_NT, MP_OCC) void conv3x3_rgb_pool_mfma(ConvKernelArgs p, int Hp, int Wp, int tiles_y, int tiles_x, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char mp_smem[];
     float4 *rgb = reinterpret_cast<float4 *>(mp_smem);              // [hi r g b 0 | lo r g b 0] per input pixel
     float *conv = reinterpret_cast<float *>(mp_smem + MP_IR * MP_IC * 16);
@@ -353,7 +347,7 @@ void launch_conv_pool(const ConvKernelArgs &k, hipStream_t s) {
     const int tiles_y = (Hp + PTH - 1) / PTH, tiles_x = (Wp + PTW - 1) / PTW, n_tiles = n_img * tiles_y * tiles_x;
     if (conv_math() == MATH_F16X3 && !getenv("YDS_POOL_VALU")) {    // matrix-core version (exact fp32 mode keeps the fma chain)
         const int ty = (Hp + MP_TH - 1) / MP_TH, tx = (Wp + MP_TW - 1) / MP_TW, nt = n_img * ty * tx;
-        dim3 g((unsigned)std::min(nt, 256 * YDS_MP_OCC));
+        dim3 g((unsigned)std::min(nt, 256 * MP_OCC));
         constexpr int smem = MP_IR * MP_IC * 16 + MP_CONV * MP_LD * 4;
         static bool attr_set = false;
         if (!attr_set) {

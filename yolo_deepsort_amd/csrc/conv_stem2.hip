@@ -22,9 +22,6 @@
 
 #include <algorithm>
 
-#ifndef YDS_STEM_ABL
-#define YDS_STEM_ABL 0     // experiment builds: 1 no phase A (layer 0), 2 no phase B (MFMAs), 3 no epilogue
-#endif
 
 namespace yds {
 
@@ -124,7 +121,7 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
         fetch(tl + gridDim.x);
         // ---- phase A: layer 0 for the 17 x 33 patch as 18 fragments of 32 pixels (wave w takes fragments w, w + 8, w + 16)
 #pragma unroll 1
-        for (int fr = wave; fr < (YDS_STEM_ABL == 1 ? 0 : (PATCH_ROWS + 31) / 32); fr += NW) {
+        for (int fr = wave; fr < (PATCH_ROWS + 31) / 32; fr += NW) {
             const int pix = fr * 32 + (lane & 31), pc = min(pix, PATCH_ROWS - 1);
             const int ry = pc / PC, rc = pc - ry * PC;
             f32x16 c1, c2;
@@ -172,7 +169,7 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc1[0][0][e] = 0.f; acc2[0][0][e] = 0.f; }
 #pragma unroll
-        for (int t = 0; t < (YDS_STEM_ABL == 2 ? 0 : 9); ++t) {
+        for (int t = 0; t < 9; ++t) {
             const int dy = t / 3, dx = t % 3;
             const int j = (dx & 1) ? ODD_BASE + (2 * py + dy) * ODD_COLS + px : (2 * py + dy) * EVEN_COLS + px + (dx >> 1);
             const int jsw = (j >> 1) & 7, wrow = t * BN + brow, wsw = (wrow >> 1) & 7;
@@ -191,7 +188,6 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[0][0][e] = (acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
         // the staging area (32 x 68 floats) lives in the RGB tile, which phase A is done with
-        if (YDS_STEM_ABL == 3) { if (acc1[0][0][0] == 123.456f) p1.y[0] = 1.f; continue; }
         conv_epilogue_rows<BM, BN, WM, WN, ACT1, RES_NONE, 1, 1, NT, StemRows>(p1, acc1, reinterpret_cast<float *>(rgb),
                                                                                  StemRows{img, oy0, ox0, p1.Ho, p1.Wo}, 0, tid);
     }

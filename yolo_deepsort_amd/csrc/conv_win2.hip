@@ -14,24 +14,9 @@
 // ANY base row, which is what the shifted tap windows need.
 #include "conv_common.h"
 
-#ifndef YDS_WIN2_ORDER
-#define YDS_WIN2_ORDER 1     // 1: fragments of the next step in the first MFMA slots, DMA pieces after (measured: faster on 6 of 8 shapes); 0: DMA first
-#endif
-
-#ifndef YDS_WIN2_SKEW
-#define YDS_WIN2_SKEW 0     // measured: the skewed step (last MFMAs of step t-1 issued after the barrier of step t) is no faster, 3-8 % slower for a lone workgroup
-#endif
-#ifndef YDS_WIN2_TERM_MAJOR
-#define YDS_WIN2_TERM_MAJOR 0     // measured: term-major MFMA order is 3-5 % slower at batch 16 and equal for a lone workgroup
-#endif
-#ifndef YDS_TIMING2
-#define YDS_TIMING2 0                     // experiment: s_memtime phase accounting (conv_win2_debug_prof)
-#endif
-
 namespace yds {
 
-__device__ unsigned long long yds_prof2[8];
-__device__ unsigned long long yds_clk_win2[2];  // sustained shader clock inside the kernel: (cycles, 100 MHz ticks) of one workgroup in 32 (see conv_win.hip)    // wait, barrier, body, prologue, epilogue, total, steps, waves (YDS_TIMING2 builds)
+__device__ unsigned long long yds_clk_win2[2];  // sustained shader clock inside the kernel: (cycles, 100 MHz ticks) of one workgroup in 32 (see conv_win.hip)
 
 namespace {
 
@@ -43,7 +28,7 @@ constexpr int B_INST2 = BN2 / (16 * NW2);       // filter DMA instructions per w
 constexpr int MAX_WROWS2 = 384;
 
 template <int ACT, int RES, int TERMS>
-__global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, int wrows, int apw, int stagger) {
+__global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, int wrows, int apw) {
     constexpr int WM = 2, WN = 2, TM = 2, TN = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int WB = wrows * ROW2;                                 // bytes per window buffer
@@ -64,14 +49,6 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     const bool clk_sample = tid == 0 && (blockIdx.x & 31) == 0;
     unsigned long long clk_c0 = 0, clk_w0 = 0;
     if (clk_sample) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = wall_clock64(); }
-    // Phase offset between the two workgroups of a CU: every workgroup of a launch starts at the same instant, so all of
-    // them reach their prologue (window + filters) and their epilogue (output + residual, HBM bound) TOGETHER and the matrix
-    // cores idle meanwhile - about half of a tile's time.  The second workgroup of every CU (blocks 256..511 of the first
-    // wave of dispatches) therefore starts `stagger` x 8128 cycles late; slots are refilled as they free up, so the offset
-    // carries through the whole launch and one workgroup of a CU computes while the other one moves data.
-    if (stagger && blockIdx.x < 512 && ((blockIdx.x >> 8) & 1))
-        for (int q = 0; q < stagger; ++q) __builtin_amdgcn_s_sleep(127);
-
     const int W = p.W, G = p.Cin / 32, HG = 2 * G;               // half groups
     const int drow = lane >> 2, dpos = lane & 3;
     const int npieces = wrows / 16;
@@ -150,11 +127,7 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     // into the same registers; issued back to back (tile-major order) the second one waits for the first one's result -
     // 64 cycles of latency against 32 of issue - which a wave that has its SIMD to itself cannot hide.
     auto mfma = [&](int buf, int m) {
-#if YDS_WIN2_TERM_MAJOR
-        const int term = m / (TM * TN), ij = m % (TM * TN), i = ij / TN, j = ij % TN;
-#else
         const int ij = m / 3, term = m % 3, i = ij / TN, j = ij % TN;
-#endif
         if (TERMS == 1 && term != 0) return;
         const h8 ah = fr[buf][2 * i], al = fr[buf][2 * i + 1], bh = fr[buf][2 * (TM + j)], bl = fr[buf][2 * (TM + j) + 1];
         if (term == 0) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[i][j], 0, 0, 0);
@@ -163,10 +136,6 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     };
     // fragment order: the operands of accumulator tile (0,0) first (tile-major MFMAs) / all hi halves first (term-major)
     auto frag_order = [&](int k) {
-#if YDS_WIN2_TERM_MAJOR
-        const int order[NF] = {0, 2 * TM, 2 * TM + 2, 2, 2 * TM + 1, 2 * TM + 3, 1, 3};      // A0h B0h B1h A1h | B0l B1l | A0l A1l
-        return order[k];
-#endif
         if (k < 2) return k;                    // A0h, A0l
         if (k < 4) return 2 * TM + (k - 2);     // B0h, B0l
         if (k < 6) return 2 * TM + 2 + (k - 4); // B1h, B1l
@@ -185,9 +154,6 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
         }
     };
 
-    unsigned long long c_wait = 0, c_bar = 0, c_body = 0, c_steps = 0, c_prev = 0;
-    const unsigned long long c_start = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0;
-    const unsigned long long w_start = YDS_TIMING2 == 2 ? wall_clock64() : 0;                 // constant 100 MHz: effective shader clock = cycles / ticks
     // Step t = (hg, TAP); fragments of step t sit in fr[PAR] (read during step t-1).
     //   top      s_waitcnt vmcnt(N) + lgkmcnt(0), s_barrier: stage t+1 (fetched during step t-3) and - before a new half group -
     //            its window have landed for every wave; every wave has finished READING stage t, so its slot can be refilled
@@ -205,63 +171,25 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
         constexpr int N_OUT = !LAST || TAP <= 5 ? 2 * B_INST2 : (TAP == 6 ? B_INST2 : 0);
         const int hg1 = TAP + 1 >= 9 ? hg + 1 : hg, hg4 = TAP + 4 >= 9 ? hg + 1 : hg;
         const int slot0 = (hg + TAP) & 3;                        // ring slot of stage t: t = 9*hg + TAP, 9 = 1 mod 4
-        unsigned long long q0 = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0, q1 = q0, q2 = q0;
         if (NEXT) {
             wait_vmcnt<N_OUT>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (YDS_TIMING2) q1 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
-            if (YDS_TIMING2) q2 = __builtin_amdgcn_s_memtime();
             tap_addr(hg1, TAP1);
         }
         const char *bst1 = bring + ((slot0 + 1) & 3) * B_STAGE2;
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NDMA = 1 + B_INST2;
-#if YDS_WIN2_SKEW
-        // Skewed step: the last SKEW MFMAs of step t-1 are issued AFTER this step's barrier, under the DMA pieces, and the
-        // remaining MFMAs of step t carry the fragment reads of step t+1.  The matrix pipe then still holds work while the
-        // wave waits at the top of the step (fragments, barrier) - with one MFMA-issuing wave per SIMD it used to drain there.
-        constexpr int SKEW = 3;                                 // tile (1,1): fragments A1h, A1l, B1h, B1l
-        if (TAP != 0 || hg != 0) {
-#pragma unroll
-            for (int m = NM - SKEW; m < NM; ++m) {
-                mfma(PAR ^ 1, m);
-                __builtin_amdgcn_sched_barrier(0);
-                const int o = m - (NM - SKEW);
-                if (o == 0) { if (!LAST && TAP < 6 && TAP < apw) a_piece(hg + 1, TAP); }
-                else if (o - 1 < B_INST2) { if (REFILL) b_piece(hg4, TAP4, slot0, o - 1); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            if (!LAST && TAP < 6 && TAP < apw) a_piece(hg + 1, TAP);
-#pragma unroll
-            for (int b = 0; b < B_INST2; ++b) if (REFILL) b_piece(hg4, TAP4, slot0, b);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < NM - SKEW; ++m) {
-            mfma(PAR, m);
-            __builtin_amdgcn_sched_barrier(0);
-            // fragments whose registers the skewed MFMAs above read are re-filled last
-            const int order[NF] = {0, 1, 2 * TM, 2 * TM + 1, 2, 3, 2 * TM + 2, 2 * TM + 3};
-            if (m < NF && NEXT) frag_read(bst1, PAR ^ 1, order[m]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             mfma(PAR, m);
             __builtin_amdgcn_sched_barrier(0);
-            const int o = YDS_WIN2_ORDER == 0 ? m : (m < NF ? m + NDMA : (m - NF < NDMA ? m - NF : NDMA + NF));   // operation: 0 window, 1..2 filter, 3..10 fragments
+            const int o = m < NF ? m + NDMA : (m - NF < NDMA ? m - NF : NDMA + NF);   // operation: 0 window, 1..2 filter, 3..10 fragments; the next step's fragments go first
             if (o == 0) { if (!LAST && TAP < 6 && TAP < apw) a_piece(hg + 1, TAP); }
             else if (o - 1 < B_INST2) { if (REFILL) b_piece(hg4, TAP4, slot0, o - 1); }
             else if (o - NDMA < NF) { if (NEXT) frag_read(bst1, PAR ^ 1, frag_order(o - NDMA)); }
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
-        // (no sample at the end of the body: it would wait for the fragment reads in flight and serialise the pipeline; the
-        //  body of step t is measured as q0 of step t+1 minus q2 of step t)
-        if (YDS_TIMING2 && NEXT) { c_wait += q1 - q0; c_bar += q2 - q1; if (c_prev) c_body += q0 - c_prev; c_prev = q2; ++c_steps; }
     };
     // nine taps of one half group; the step parity alternates and 9 is odd, so half groups alternate between two bodies
     auto half_group = [&](int hg, auto last_c, auto par_c) {
@@ -290,7 +218,6 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     for (int f = 0; f < NF; ++f) frag_read(bring, 0, f);
     __builtin_amdgcn_sched_barrier(0);
 
-    const unsigned long long c_loop = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0;
     // half groups 0 .. HG-1: parity of the first step of half group hg is hg & 1 (9 steps each); HG is even
     for (int hg = 0; hg + 2 < HG; hg += 2) {
         half_group(hg, std::false_type{}, std::integral_constant<int, 0>{});
@@ -299,11 +226,6 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     half_group(HG - 2, std::false_type{}, std::integral_constant<int, 0>{});
     half_group(HG - 1, std::true_type{}, std::integral_constant<int, 1>{});
 
-#if YDS_WIN2_SKEW
-#pragma unroll
-    for (int m = NM - 3; m < NM; ++m) mfma(1, m);               // the skewed MFMAs of the last step (its fragments sit in fr[1])
-#endif
-    const unsigned long long c_end = YDS_TIMING2 ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads();                                            // every wave is done with the windows and the ring
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -316,15 +238,6 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
     if (clk_sample) {
         atomicAdd(&yds_clk_win2[0], __builtin_amdgcn_s_memtime() - clk_c0);
         atomicAdd(&yds_clk_win2[1], wall_clock64() - clk_w0);
-    }
-    if (YDS_TIMING2) {
-        __syncthreads();
-        if (tid == 0 && (blockIdx.x & 15) == 0) {                // a sample of the workgroups: same-address atomics of every wave would dominate the launch
-            const unsigned long long c_fin = __builtin_amdgcn_s_memtime();
-            atomicAdd(&yds_prof2[0], YDS_TIMING2 == 2 ? wall_clock64() - w_start : c_wait); atomicAdd(&yds_prof2[1], c_bar); atomicAdd(&yds_prof2[2], c_body);
-            atomicAdd(&yds_prof2[3], c_loop - c_start); atomicAdd(&yds_prof2[4], c_fin - c_end); atomicAdd(&yds_prof2[5], c_fin - c_start);
-            atomicAdd(&yds_prof2[6], c_steps); atomicAdd(&yds_prof2[7], 1ull);
-        }
     }
 }
 
@@ -341,9 +254,7 @@ template <int ACT, int RES, int TERMS = 3> void launch_inst_win2(ConvKernelArgs 
         attr_set = smem;
     }
     dim3 grid(plan_tile_map(k, BM2, BN2));
-    static const int stagger_env = getenv("YDS_WIN2_STAGGER") ? atoi(getenv("YDS_WIN2_STAGGER")) : -1;
-    const int stagger = stagger_env >= 0 ? stagger_env : 0;
-    hipLaunchKernelGGL(kern, grid, dim3(NT2), smem, s, k, wrows, apw, stagger);
+    hipLaunchKernelGGL(kern, grid, dim3(NT2), smem, s, k, wrows, apw);
     YDS_HIP(hipGetLastError());
 }
 
@@ -361,14 +272,6 @@ void conv_win2_clock(unsigned long long *cycles_ticks, bool reset) {
     if (reset) {
         unsigned long long z[2] = {};
         YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_clk_win2), z, sizeof z));
-    }
-}
-
-void conv_win2_debug_prof(unsigned long long *out, bool reset) {
-    YDS_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(yds_prof2), sizeof(unsigned long long) * 8));
-    if (reset) {
-        unsigned long long z[8] = {};
-        YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_prof2), z, sizeof(z)));
     }
 }
 

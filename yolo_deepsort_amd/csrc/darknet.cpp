@@ -958,14 +958,6 @@ int yds_conv_clock(double *ghz, double *sampled_ms, int reset) {
     if (sampled_ms) *sampled_ms = ticks * 1e-5;
     YDS_API_END
 }
-int yds_debug_prof(uint64_t *out8, int reset) {
-    YDS_API_BEGIN
-    unsigned long long v[8];
-    if (reset & 2) yds::conv_win2_debug_prof(v, (reset & 1) != 0);      // bit 1: the two-workgroup window kernel's counters
-    else yds::conv_debug_prof(v, reset != 0);
-    for (int i = 0; i < 8; ++i) out8[i] = v[i];
-    YDS_API_END
-}
 int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int res_mode, const float *x_nhwc,
                  const float *w_okkc, const float *bias, const float *res_nhwc, float *y_nchw) {
     YDS_API_BEGIN
