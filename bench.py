@@ -10,6 +10,10 @@ Rank 0 prints ONE JSON line:
   value               frames/s with the frames already resident in HBM when the timed region starts (the contract's metric)
   value_with_upload   the same K steps with the frames handed over as pinned HOST memory and uploaded inside the step
                       (yds_pipeline_step_host: copy stream, double buffered) - the PCIe-inclusive rate
+  value_other_schedule  the same K steps under the other stream schedule (config.schedule names the one `value` ran under:
+                      "serialized" = the ReID pass of batch i is enqueued on the detector's stream between the first layers of pass
+                      i+1 and the rest, every conv kernel has the chip to itself; "two-stream" = both passes share the CUs;
+                      results are identical, pipeline.cpp explains the policy)
   value_f32_math      a short run of the same workload on the exact-fp32 MFMA kernels (dtype of `value` is f16x3)
   value_frame_by_frame  one frame in, one result out (batch_frames = 1, nothing enqueued ahead: the reference's own loop,
                       video_detect.py:124-157); value_frame_by_frame_lookahead1 hands the next frame over one step early
@@ -136,9 +140,9 @@ def roofline_json(dom, allc, B, peak_note, traffic=None):
     rec = dict(bound="mfma", kernel=dom["kernel"], achieved=r(dom["achieved"], 2), peak=r(dom["peak"], 1), unit="TFLOP/s", frac=r(dom["frac"]),
                traffic=None,
                timing="HIP event pairs around every conv launch on the detector stream, no host synchronisation inside a pass.  achieved / "
-                      "avg_launch_us / frac = IN THE PIPELINE: a repeat of the K timed steps (prefetched, ReID / association streams live) - the "
-                      "conditions `value` was measured under and what a rocprofv3 kernel-trace summary of this command shows; *_isolated = two "
-                      "non-prefetched steps (conv stream alone)",
+                      "avg_launch_us / frac = IN THE PIPELINE: a repeat of the K timed steps (prefetched, ReID pass and association live, under "
+                      "the schedule named in `schedule`) - the conditions `value` was measured under and what a rocprofv3 kernel-trace summary "
+                      "of this command shows; *_isolated = two non-prefetched steps (conv stream alone)",
                avg_launch_us=r(dom["avg_launch_us"], 2), launches=dom["launches"],
                achieved_isolated=r(dom["achieved_isolated"], 2), frac_isolated=r(dom["frac_isolated"]), avg_launch_us_isolated=r(dom["avg_launch_us_isolated"], 2),
                peak_note=peak_note, frac_of_attainable=r(dom["frac_of_attainable"]),
@@ -182,6 +186,9 @@ def main():
     ap.add_argument("--dump-rows", default=None, help="rank 0 saves every stream's tracker rows of the timed steps (npz: s<stream>_k<step>_f<frame>)")
     ap.add_argument("--latency-steps", type=int, default=150, help="frames of the frame-by-frame legs (0 = skip)")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--schedule", default="policy", choices=["policy", "serialized", "two-stream"],
+                    help="ReID pass of batch i vs detector pass of batch i+1: serialized on one stream or sharing the CUs from two (yds_pipeline_set_schedule); "
+                         "policy = the library's own choice (serialized for yolov3, two streams for yolov4: pipeline.cpp)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")
@@ -228,6 +235,8 @@ def main():
     wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
     cfg = wl.cfg
     wl.to_device()
+    sched_arg = {"policy": None, "serialized": 0, "two-stream": -1}[args.schedule]
+    wl.pipe.set_schedule(sched_arg)
 
     def sync():
         _lib.check(lib.yds_device_sync())
@@ -251,6 +260,7 @@ def main():
     rank_values = ranks.gather_objects(round(K * B / dt_own, 2))        # every rank's own frames/s over its own clock around the K steps
     flops_frame = wl.flops_per_frame()
     stage = wl.pipe.stage_us()
+    schedule = wl.pipe.last_schedule()
     math_name = {0: "f32", 1: "f16x3", 2: "f16"}[lib.yds_get_conv_math()] if not args.half else "f16"
     # dtype: the arithmetic type the conv path computes in.  f16x3 = both operands as two-term fp16 expansions (22 significant bits), exact
     # fp16 products, fp32 accumulation - the reference's fp32 class; f32 = v_mfma_f32_32x32x2_f32
@@ -260,12 +270,20 @@ def main():
     if not args.no_extras:
         dt_up, _ = timed_steps(wl, ranks, sync, K, W, W + K, host_frames=True)
 
+    # ---- the same K steps under the OTHER schedule (results are identical; the line carries both rates)
+    other = None
+    if not args.no_extras:
+        wl.pipe.set_schedule(-1 if schedule == "serialized" else 0)
+        dt_o, _ = timed_steps(wl, ranks, sync, K, W, 2 * (W + K), host_frames=False)
+        other = {"schedule": wl.pipe.last_schedule(), "value": round(ranks.total_frames(K, B) / dt_o, 2)}
+        wl.pipe.set_schedule(sched_arg)
+
     roofline, variants = None, None
     if not args.no_roofline:
         # (every rank runs the leg - its steps contain the exchange step - rank 0 reports)
         f16x3 = lib.yds_get_conv_math() == 1 and not args.half
         peak = PEAK_F16_MFMA_TFLOPS / 3 if f16x3 else (PEAK_F16_MFMA_TFLOPS if args.half else PEAK_F32_MFMA_TFLOPS)
-        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, 2 * (W + K), peak)
+        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, 3 * (W + K), peak)
         if rank == 0 and dom is not None:
             note = ("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
                     else ("dense fp16 MFMA" if args.half else "fp32-input MFMA, 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz"))
@@ -274,7 +292,7 @@ def main():
                 frac_of_fp32_mfma_peak=round(dom["achieved"] / PEAK_F32_MFMA_TFLOPS, 4),
                 # pure-MFMA loop on random fp16 data, sustained (power limited): profiles/r01_ablation_dma.txt #6
                 frac_of_measured_mfma_ceiling=round(dom["achieved"] / (MEASURED_F16_MFMA_TFLOPS / 3 if f16x3 else PEAK_F32_MFMA_TFLOPS), 4),
-                fps_with_conv_events=round(ranks.total_frames(K, B) / dt_ev, 2),
+                fps_with_conv_events=round(ranks.total_frames(K, B) / dt_ev, 2), schedule=schedule,
                 # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
                 # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
                 pipeline_conv_frac=round(flops_frame * K * B / dt / 1e12 / peak, 4),
@@ -324,6 +342,7 @@ def main():
         lib.yds_set_conv_math(0)
         wl32 = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base))
         wl32.to_device()
+        wl32.pipe.set_schedule(sched_arg)
         k32 = max(3, min(K, 10))                                  # (shorter runs under-read this mode: its first steps still ramp)
         dt32, _ = timed_steps(wl32, ranks, sync, k32, 3, 0, host_frames=False)
         f32_fps = ranks.total_frames(k32, B) / dt32
@@ -334,6 +353,7 @@ def main():
                                              committed_traffic(args.config, dom32["kernel"], B, "_f32"))
                 roofline_f32["pipeline_conv_frac"] = round(flops_frame * k32 * B / dt32 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                 roofline_f32["value_f32_math"] = round(f32_fps, 2)
+                roofline_f32["schedule"] = wl32.pipe.last_schedule()
         del wl32
         lib.yds_set_conv_math(1)
 
@@ -349,12 +369,13 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": math_name, "data": "synthetic",
             "config": {"workload": cfg["workload"], "frames_per_step": B, "streams": world, "frame": "1920x1080x3 u8",
-                       "frames_in": "resident in HBM", "tracker_rows_out": n_out, "parallelism": f"stream-per-gpu x{world}",
+                       "frames_in": "resident in HBM", "tracker_rows_out": n_out, "schedule": schedule, "parallelism": f"stream-per-gpu x{world}",
                        "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices],
                        "rank_values": rank_values, **ranks.describe()},
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_with_upload is the PCIe-inclusive rate",
             "value_with_upload": None if dt_up is None else round(frames_total / dt_up, 2),
             "value_with_upload_note": "same K steps, frames handed over as pinned host memory and uploaded inside the timed region (copy stream, three staging buffers, each batch announced two steps ahead like a decoder queue)",
+            "value_other_schedule": other,
             "value_f32_math": None if f32_fps is None else round(f32_fps, 2),
             "value_frame_by_frame": None if fbf is None else round(fbf, 2),
             "value_frame_by_frame_lookahead1": None if fbf_ahead is None else round(fbf_ahead, 2),

@@ -23,13 +23,23 @@ def _rows_equal(got, ref, stats):
 
 @pytest.mark.parametrize("config", ["cfg2", "cfg3", "cfg5"])
 def test_pipeline_at_bench_shape_vs_reference(config):
-    _bench_shape(config)
+    # the library's own stream schedule: serialized for yolov3, two streams for yolov4 (pipeline.cpp)
+    assert _bench_shape(config) == ("serialized" if config == "cfg2" else "two-stream")
 
 
-def _bench_shape(config):
+@pytest.mark.parametrize("config,min_crops", [("cfg2", -1), ("cfg3", 0), ("cfg5", 0)])
+def test_pipeline_at_bench_shape_other_schedule(config, min_crops):
+    """The schedule each configuration does NOT run by default (yds_pipeline_set_schedule), against the same reference rows: the
+    ReID pass on the detector's stream between the head and the tail of the next pass (with the crowd configuration's early ReID
+    launch of the next batch behind it), or on its own stream for yolov3."""
+    assert _bench_shape(config, min_crops) == ("two-stream" if min_crops < 0 else "serialized")
+
+
+def _bench_shape(config, min_crops=None):
     from yolo_deepsort_amd.workload import Workload, CONF_THRES, NMS_THRES
     g = golden(f"bench_shape_{config}")
     wl = Workload(config, batch=16)
+    wl.pipe.set_schedule(min_crops)
     B = 16
     assert int(g["n_frames"]) == 2 * B and wl.order[:2 * B] == list(range(2 * B))
     # ---- the composed pipeline, 2 steps, the second one prefetched under the first one's association
@@ -61,6 +71,7 @@ def _bench_shape(config):
         ref = g[f"f{t}_det"]
         assert det.shape == ref.shape and np.array_equal(det[:, 5], ref[:, 5]), t
         np.testing.assert_allclose(det, ref, rtol=1e-3, atol=1e-3)
+    return wl.pipe.last_schedule()
 
 
 def test_one_step_of_32_frames_vs_reference():

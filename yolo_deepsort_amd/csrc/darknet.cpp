@@ -512,11 +512,48 @@ void Darknet::run_graph(int batch) {
     }
 }
 
-void Darknet::run_lane(int first, int batch, hipStream_t stream) {
+// Layers the pipeline enqueues as the first piece of a pass: up to the first convolution past ~6 % of the network's
+// arithmetic (yolov3 / yolov4 at 608 x 608: the stem and the first residual block, ~0.04 ms per image) - enough stream-ordered
+// work to cover the host's share of the hand-over (NMS results -> crop list -> ReID launches) without delaying that ReID pass.
+int Darknet::head_layers() const {
+    double total = 0, acc = 0;
+    for (int i = 0; i < (int)layers.size(); ++i)
+        if (layers[i].type == "convolutional") total += conv_flops(conv_args(i, 1));
+    for (int i = 0; i < (int)layers.size(); ++i) {
+        if (layers[i].type != "convolutional") continue;
+        acc += conv_flops(conv_args(i, 1));
+        if (acc >= 0.06 * total) return i + 1;
+    }
+    return (int)layers.size();
+}
+
+double Darknet::pointwise_share() const {
+    double total = 0, pw = 0;
+    for (int i = 0; i < (int)layers.size(); ++i) {
+        if (layers[i].type != "convolutional") continue;
+        const double f = conv_flops(conv_args(i, 1));
+        total += f;
+        if (layers[i].ksize == 1) pw += f;
+    }
+    return total > 0 ? pw / total : 0.0;
+}
+
+bool Darknet::forward_resized_part(int batch, int part) {
+    if (batch < 1 || batch > batch_max) fail("forward: batch %d outside [1,%d]", batch, batch_max);
+    if (math != conv_math()) fail("forward: this network was planned for conv math %d, current mode is %d (re-create it)", math, conv_math());
+    if (getenv("YDS_DET_LANES") && atoi(getenv("YDS_DET_LANES")) > 1) return false;
+    const int cut = head_layers();
+    if (part == 0) run_lane(0, batch, stream, 0, cut);
+    else run_lane(0, batch, stream, cut, -1);
+    return true;
+}
+
+void Darknet::run_lane(int first, int batch, hipStream_t stream, int l0, int l1) {
     autotune(batch);                                            // (tuning launches use the main stream; cached per image count)
     lane_img0 = first;
     struct Reset { int &v; ~Reset() { v = 0; } } reset{lane_img0};
-    for (int i = 0; i < (int)layers.size(); ++i) {
+    if (l1 < 0 || l1 > (int)layers.size()) l1 = (int)layers.size();
+    for (int i = l0; i < l1; ++i) {
         Layer &l = layers[i];
         if (l.type == "convolutional") {
             if (!l.loaded) fail("forward: layer %d has no weights (call load_darknet_weights)", i);

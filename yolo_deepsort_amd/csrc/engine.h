@@ -64,6 +64,11 @@ public:
     void forward_u8_host(const uint8_t *frames, int h, int w, int batch, float *out_host);
     void forward_u8_dev(const uint8_t *frames_dev, int h, int w, int batch);
     void forward_resized(int batch) { run_graph(batch); }      // input buffer already filled
+    // the same pass enqueued in two pieces (layers [0, head_layers()) and the rest): the pipeline puts another stream-ordered
+    // job between them (pipeline.cpp, serialized schedule); false = this configuration runs in lanes and cannot be split
+    bool forward_resized_part(int batch, int part);
+    int head_layers() const;
+    double pointwise_share() const;          // share of the network's conv arithmetic in 1x1 layers
     // sliding-window front end (img_detect.py:97-139): windows (x, y, th, tw) of one host frame -> corner-form, window-
     // shifted predictions [n_tiles * total_boxes, attrs] in tiled_pred (windows run in chunks of batch_max)
     void forward_tiles_host(const uint8_t *frame, int h, int w, const int *tiles_xyhw, int n_tiles);
@@ -122,7 +127,8 @@ public:
 private:
     void allocate_buffers();
     void run_graph(int batch);
-    void run_lane(int first, int batch, hipStream_t st);      // layers over images [first, first + batch) on one stream
+    // layers [l0, l1) over images [first, first + batch) on one stream (l1 < 0: to the end)
+    void run_lane(int first, int batch, hipStream_t st, int l0 = 0, int l1 = -1);
     bool stem_fusable = false, stem_ok = false;               // layers 0+1 as one kernel (conv_stem2.hip)
     int stem_checked = -1;
     bool stem_fused(int batch);
@@ -203,6 +209,13 @@ public:
     DevBuf<uint8_t> stage_u8;
     DevBuf<int> boxes_dev;
     std::vector<int> boxes_host;
+    // crop rectangles of the batched pass, in PINNED host memory the crop kernel reads in place (19 KB for 960 crops): no
+    // host-to-device copy command on the stream - a pageable hipMemcpyAsync stalls the host behind everything queued on that
+    // stream and shares the copy engine with the frame uploads.  Two buffers alternate (a pass may be enqueued while the crop
+    // kernel of the previous one has not run yet).
+    int *boxes_pin[2] = {nullptr, nullptr};
+    size_t boxes_pin_cap[2] = {0, 0};
+    int boxes_pin_turn = 0;
     std::map<int, std::pair<int, int>> tuned;   // conv index -> (D at measurement, measured tile variant)
     int tuned_math = -1;
     hipStream_t stream = nullptr;

@@ -15,6 +15,7 @@
 // under MFMA work.
 #include "engine.h"
 
+#include <limits.h>
 #include <stdlib.h>
 
 #include <chrono>
@@ -25,6 +26,7 @@ class Pipeline {
 public:
     Pipeline(Darknet *net, ReidNet *reid, TrackerIface *trk, float conf, float nms_iou, const int32_t *mask, int n_mask)
         : net(net), reid(reid), trk(trk), conf(conf), nms_thres(nms_iou), class_mask(mask, mask + n_mask) {
+        net_pointwise_share = net->pointwise_share();
         for (int k = 0; k < 2; ++k) {
             for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
             nms[k].reset(new NmsWorkspace(4096, net->batch_max));
@@ -32,6 +34,7 @@ public:
         for (int k = 0; k < NSTAGE; ++k)
             for (hipEvent_t *e : {&up_done[k], &rd_det[k], &rd_reid[k]}) YDS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         YDS_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        YDS_HIP(hipEventCreateWithFlags(&ev_feat, hipEventDisableTiming));
     }
     ~Pipeline() {
         for (int k = 0; k < 2; ++k) {
@@ -40,6 +43,7 @@ public:
         for (int k = 0; k < NSTAGE; ++k)
             for (hipEvent_t e : {up_done[k], rd_det[k], rd_reid[k]}) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(copy_stream);
+        (void)hipEventDestroy(ev_feat);
     }
 
     // ---- frames handed over as HOST memory (img_detect.py:70-71 starts from a host frame) ------------------------------
@@ -100,7 +104,7 @@ public:
             next_k = staged(next_host);
             if (next_k < 0) next_k = upload(next_host, bytes, 2, cur_k);              // survives this step: the next call's `frames`
         }
-        step(stage[cur_k].p, next_k >= 0 ? stage[next_k].p : nullptr, next_inject_set, h, w, batch, out6, cap, counts);
+        step(stage[cur_k].p, next_k >= 0 ? stage[next_k].p : nullptr, next_inject_set, h, w, batch, out6, cap, counts, true);
         // every host buffer handed over so far may be reused by the caller when this returns; the consumed batch is forgotten
         for (int k = 0; k < NSTAGE; ++k)
             if (up_pending[k]) { YDS_HIP(hipEventSynchronize(up_done[k])); up_pending[k] = false; }
@@ -119,7 +123,15 @@ public:
     // their pinned result buffers) alternate, so that the pass of batch i+1 can be enqueued before the host has waited
     // for and read the results of batch i: the detector stream never drains between passes.
     void launch_detector(const uint8_t *frames_dev, int h, int w, int batch, int slot = -1) {
+        launch_detector_head(frames_dev, h, w, batch, slot, false);
+        launch_detector_tail(frames_dev, h, w, batch);
+    }
+    // The pass in two pieces (serialized schedule, see step()): head = upload wait + resize + the first layers
+    // (Darknet::head_layers), tail = the remaining layers + NMS.  split = false (or a network that cannot be split) puts the whole
+    // network into the tail.
+    void launch_detector_head(const uint8_t *frames_dev, int h, int w, int batch, int slot, bool split) {
         const int k = slot >= 0 ? slot : (in_flight_slot ^= 1);
+        head_slot = k;
         for (int b = 0; b < NSTAGE; ++b)                            // frames uploaded by step_host: wait for the copy engine
             if (stage[b].p && frames_dev == stage[b].p && hipEventQuery(up_done[b]) != hipSuccess)
                 YDS_HIP(hipStreamWaitEvent(net->stream, up_done[b], 0));   // (only while the copy is still running: see step())
@@ -127,7 +139,12 @@ public:
         launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream);
         YDS_HIP(hipEventRecord(e1[k], net->stream));
         if (const int sl = slot_of(frames_dev); sl >= 0) { YDS_HIP(hipEventRecord(rd_det[sl], net->stream)); rd_det_set[sl] = true; }
-        net->forward_resized(batch);
+        head_split = split && net->forward_resized_part(batch, 0);
+    }
+    void launch_detector_tail(const uint8_t *frames_dev, int h, int w, int batch) {
+        const int k = head_slot;
+        if (head_split) (void)net->forward_resized_part(batch, 1);
+        else net->forward_resized(batch);
         YDS_HIP(hipEventRecord(e2[k], net->stream));
         const float sx = (float)((double)w / net->img_w), sy = (float)((double)h / net->img_h);
         nms[k]->launch(net->out.p, (size_t)net->total_boxes * net->attrs, batch, net->total_boxes, net->attrs, conf, nms_thres, sx, sy, 300,
@@ -144,6 +161,7 @@ public:
         const uint8_t *frames = nullptr;
         int batch = 0;
         bool reid_in_flight = false;
+        hipStream_t reid_on = nullptr;            // stream the ReID pass of this batch was enqueued on
     };
 
     // wait for the detector pass + NMS enqueued in slot k, build the detection lists
@@ -157,9 +175,12 @@ public:
             YDS_HIP(hipStreamSynchronize(net->stream));
             nms[k]->resize(nms[k]->needed(batch), nms[k]->frames);
             const uint8_t *keep = in_flight;
-            const int keep_batch = in_flight_batch;
+            const int keep_batch = in_flight_batch, keep_head = head_slot;
+            const bool keep_split = head_split;
             launch_detector(frames_dev, last_h, last_w, batch, k);
             in_flight = keep; in_flight_batch = keep_batch;      // the prefetched pass (if any) is still the one in flight
+            head_slot = keep_head; head_split = keep_split;
+            head_stale = true;                                   // ... but a head enqueued for the next pass has been overwritten
             YDS_HIP(hipEventSynchronize(e_nms[k]));
         }
         float ms01 = 0, ms12 = 0;
@@ -186,50 +207,105 @@ public:
         }
     }
     // one ReID pass over the crops of the whole batch, asynchronous on the extractor's stream
-    void launch_reid(Dets &d, int h, int w) {
+    // `on` = the detector's stream: the pass is SERIALIZED with the detector passes (stream order) instead of sharing the CUs
+    // with them from the extractor's own stream
+    void launch_reid(Dets &d, int h, int w, hipStream_t on = nullptr) {
+        d.reid_on = on ? on : reid->stream;
         if (!d.payload.empty()) {
+            struct Swap { hipStream_t &s; hipStream_t keep; ~Swap() { s = keep; } } swap{reid->stream, reid->stream};
+            reid->stream = d.reid_on;
             reid->embed_multi_dev(d.frames, h, w, d.tlwh.data(), d.frame_of.data(), (int)d.payload.size());
-            if (const int sl = slot_of(d.frames); sl >= 0) { YDS_HIP(hipEventRecord(rd_reid[sl], reid->stream)); rd_reid_set[sl] = true; }
+            if (const int sl = slot_of(d.frames); sl >= 0) { YDS_HIP(hipEventRecord(rd_reid[sl], d.reid_on)); rd_reid_set[sl] = true; }
         }
         d.reid_in_flight = true;
     }
 
     void step(const uint8_t *frames_dev, const uint8_t *next_frames_dev, int next_inject_set, int h, int w, int batch, int32_t *out6,
-              int cap, int32_t *counts) {
+              int cap, int32_t *counts, bool uploaded = false) {
         using clk = std::chrono::steady_clock;
         auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::micro>(b - a).count(); };
         if (batch < 1 || batch > net->batch_max) fail("pipeline: batch %d outside [1,%d]", batch, net->batch_max);
         auto t_begin = clk::now();
         last_h = h; last_w = w;
         const bool resumed = ahead.reid_in_flight && ahead.frames == frames_dev && ahead.batch == batch;
+        // Serialized schedule (round 4).  The ReID pass of batch i and the detector pass of batch i+1 are both chip-filling
+        // sequences of matrix-core kernels; from two streams they time-share the CUs, every launch stretched by the other
+        // stream's work (1.3x on the detector's kernels at cfg2) for the same total.  With >= serial_min crops in the batch the
+        // ReID pass is enqueued on the DETECTOR's stream instead, between the head of the next pass (resize + first layers,
+        // already queued while the host waited for this batch's NMS and built the crop list: the stream never drains) and its
+        // tail: every conv kernel then has the chip to itself, a launch takes its isolated time, and only the association's
+        // small kernels (own high-priority stream) run beside them.  Smaller batches (the frame-by-frame API) keep the two-stream
+        // form - a 30-crop ReID pass cannot fill the chip and gains from running beside the detector.
+        // Measured (tools/ab_serial.sh, tools/ab_upload.sh, profiles/r04_serial_schedule_ab.txt; boxes differ by +-1 %), two-stream ->
+        // serialized, 32 frames per step:
+        //   cfg2 yolov3, frames resident in HBM   1505-1525 -> 1518-1527 frames/s (equal), window kernel 423 -> 303 us per launch
+        //                                         in the pipeline (isolated: 316), exact-fp32 mode 561-569 -> 556-560
+        //   cfg2, frames uploaded inside the step 1469-1508 -> 1426-1436 (-4 %: +1.3 ms per step on the detector's stream that
+        //                                         neither the copy's start time nor the result read-back explains - open)
+        //   cfg3 yolov4 1456 -> 1415 (-3 %), cfg5 yolov4 crowd 672 -> 660 (-2 %)
+        // yolov4 spends 19 % of its arithmetic (a third of its time) in HBM-bound 1x1 Mish layers, which do gain from sharing the
+        // chip with the MFMA-bound ReID pass; yolov3 (10 %) does not.  Policy: serialize from 256 crops per batch when the
+        // detector's 1x1 share is below 15 % and the frames are already in HBM (yds_pipeline_step); two streams otherwise.
+        // yds_pipeline_set_schedule / YDS_PIPE_SERIAL=<crops> force a threshold for any network and entry, -1 = never.
+        const int serial_min = schedule_min_crops != INT_MIN ? schedule_min_crops
+                               : getenv("YDS_PIPE_SERIAL")  ? atoi(getenv("YDS_PIPE_SERIAL"))
+                               : (net_pointwise_share < 0.15 && !uploaded ? 256 : -1);
         int next_slot = -1;
-        auto launch_next = [&]() {                                  // detector (+ NMS) of the next batch goes in flight
+        bool next_head_only = false;
+        auto launch_next = [&](bool head_only) {                    // detector (+ NMS) of the next batch goes in flight
             if (!next_frames_dev) return;
             if (next_inject_set >= 0) net->select_injection_set(next_inject_set);      // bench-only logit injection
-            launch_detector(next_frames_dev, h, w, batch);
+            if (head_only) {
+                head_stale = false;
+                launch_detector_head(next_frames_dev, h, w, batch, -1, true);
+                next_head_only = true;
+            } else {
+                launch_detector(next_frames_dev, h, w, batch);
+            }
             next_slot = in_flight_slot;
         };
+        auto launch_next_tail = [&]() {
+            if (!next_head_only) return;
+            if (head_stale) launch_detector_head(next_frames_dev, h, w, batch, head_slot, true);    // (overwritten by a redone pass)
+            launch_detector_tail(next_frames_dev, h, w, batch);
+            next_head_only = false;
+        };
+        auto copy_feats = [&]() {
+            // the tracker reads its own copy so that the extractor can start on the next batch during the association
+            if (cur.payload.empty()) return;
+            feat_cur.ensure((size_t)reid->max_crops * 512);
+            YDS_HIP(hipMemcpyAsync(feat_cur.p, reid->feat.p, cur.payload.size() * 512 * sizeof(float), hipMemcpyDeviceToDevice, cur.reid_on));
+            YDS_HIP(hipEventRecord(ev_feat, cur.reid_on));
+        };
+        bool serial = false;
         if (resumed) {
             std::swap(cur, ahead);                                  // NMS done and ReID already running since the previous call
             ahead.reid_in_flight = false;
-            launch_next();
+            serial = cur.reid_on == net->stream;
+            copy_feats();                                           // (behind that ReID pass, ahead of the next detector pass)
+            launch_next(false);
         } else {
             ahead.reid_in_flight = false;
             if (in_flight != frames_dev || in_flight_batch != batch) launch_detector(frames_dev, h, w, batch);
             const int slot = in_flight_slot;
             in_flight = nullptr;
-            launch_next();                                          // enqueued BEFORE the host waits for this batch's NMS
+            launch_next(serial_min >= 0);                           // enqueued BEFORE the host waits for this batch's NMS
             finish_detector(cur, slot, frames_dev, batch);
+            serial = serial_min >= 0 && (int)cur.payload.size() >= std::max(serial_min, 1);
+            if (serial) {
+                launch_reid(cur, h, w, net->stream);
+                copy_feats();
+                launch_next_tail();
+            } else {
+                launch_next_tail();
+                launch_reid(cur, h, w);
+                copy_feats();
+            }
         }
+        last_serial = serial;
         auto t_nms = clk::now();
-        if (!resumed) launch_reid(cur, h, w);
         const int D_all = (int)cur.payload.size();
-        if (D_all) {
-            // the tracker reads its own copy so that the extractor can start on the next batch during the association
-            feat_cur.ensure((size_t)reid->max_crops * 512);
-            YDS_HIP(hipMemcpyAsync(feat_cur.p, reid->feat.p, (size_t)D_all * 512 * sizeof(float), hipMemcpyDeviceToDevice, reid->stream));
-            YDS_HIP(hipStreamSynchronize(reid->stream));
-        }
+        if (D_all) YDS_HIP(hipEventSynchronize(ev_feat));
         auto t_reid = clk::now();
         // Crowded scenes (the association of a batch takes long and is all small latency-bound kernels and host syncs):
         // before associating, finish the next batch's detector + NMS and start its ReID pass, so that the matrix
@@ -238,7 +314,7 @@ public:
         if (next_frames_dev && D_all >= deep_min * batch) {
             finish_detector(ahead, next_slot, next_frames_dev, batch);
             in_flight = nullptr;
-            launch_reid(ahead, h, w);
+            launch_reid(ahead, h, w, serial ? net->stream : nullptr);
         }
         // association of the whole batch, frame after frame on the tracker's stream, one host synchronisation
         std::vector<char> skip(batch, 0);
@@ -273,6 +349,12 @@ public:
     const uint8_t *in_flight = nullptr;
     int in_flight_batch = 0;
     hipEvent_t e0[2] = {}, e1[2] = {}, e2[2] = {}, e_nms[2] = {};
+    hipEvent_t ev_feat = nullptr;      // this batch's embeddings have been copied for the tracker
+    double net_pointwise_share = 0;
+    int schedule_min_crops = INT_MIN;  // yds_pipeline_set_schedule: crops per batch from which the ReID pass is serialized (INT_MIN: policy)
+    bool last_serial = false;          // schedule of the last step
+    int head_slot = 0;                 // NMS slot of the pass whose head was enqueued last
+    bool head_split = false, head_stale = false;
     float stage_us[5] = {0, 0, 0, 0, 0};
 };
 
@@ -314,6 +396,14 @@ int yds_pipeline_set_next_injection(yds_pipe *p, int set) {
     YDS_API_BEGIN
     p->p->next_inject_set = set;
     YDS_API_END
+}
+int yds_pipeline_set_schedule(yds_pipe *p, int min_crops) {
+    YDS_API_BEGIN
+    p->p->schedule_min_crops = min_crops < -1 ? INT_MIN : min_crops;
+    YDS_API_END
+}
+int yds_pipeline_last_schedule(yds_pipe *p) {
+    return p && p->p->last_serial ? 1 : 0;
 }
 int yds_pipeline_stage_us(yds_pipe *p, float *us5) {
     YDS_API_BEGIN

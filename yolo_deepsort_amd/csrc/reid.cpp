@@ -27,7 +27,8 @@ ReidNet::ReidNet(int max_crops) : max_crops(max_crops) {
     stream = make_stream(false);
 }
 ReidNet::~ReidNet() {
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    for (int *b : boxes_pin) if (b) (void)hipHostFree(b);
 }
 
 void ReidNet::load_tensor(const std::string &name, const float *data, const int64_t *shape, int ndim) {
@@ -234,9 +235,15 @@ void ReidNet::embed_multi_dev(const uint8_t *frames_dev, int h, int w, const flo
     if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
     reserve(D);
     crop_boxes_host(tlwh_host, D, h, w, boxes_host, frame_of);
-    boxes_dev.upload(boxes_host.data(), boxes_host.size(), stream);      // boxes_host outlives the copy (member)
+    const int t = boxes_pin_turn ^= 1;
+    if (boxes_pin_cap[t] < boxes_host.size()) {
+        if (boxes_pin[t]) { YDS_HIP(hipStreamSynchronize(stream)); (void)hipHostFree(boxes_pin[t]); boxes_pin[t] = nullptr; }
+        boxes_pin_cap[t] = std::max<size_t>(boxes_host.size() * 2, 4096);
+        YDS_HIP(hipHostMalloc((void **)&boxes_pin[t], boxes_pin_cap[t] * sizeof(int), hipHostMallocDefault));
+    }
+    memcpy(boxes_pin[t], boxes_host.data(), boxes_host.size() * sizeof(int));
     View x0; x0.p = in.p; x0.n = D; x0.h = CROP_H; x0.w = CROP_W; x0.c = 4; x0.ld = 4;
-    launch_crop_resize(frames_dev, h, w, boxes_dev.p, D, x0, stream);
+    launch_crop_resize(frames_dev, h, w, boxes_pin[t], D, x0, stream);
     forward(D);
 }
 

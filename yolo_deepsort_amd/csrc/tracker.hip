@@ -353,7 +353,7 @@ public:
     struct FrameIn { const float *tlwh; const float *feats; bool feats_on_device; const int *feat_rows; const float *payload; int D; };
 
     // Enqueues one frame; T_ub = host-side upper bound of the live track count when it starts.  Returns the int offset of
-    // this frame's result block inside res_host / res_dev.
+    // this frame's result block inside res_host (pinned host memory the kernels store into: no copy command at the end).
     size_t enqueue(const FrameIn &f, int T_ub, size_t in_off, size_t res_off, size_t *res_len, int *out_cap) {
         const int D = f.D, Dn = std::max(D, 1), Tn = std::max(T_ub, 1);
         // ---- inputs: tlwh, payload (and feat_rows) were packed into in_host by the caller; one H2D per batch
@@ -385,7 +385,7 @@ public:
         d.res_out6 = M_COUNT; d.res_matches = d.res_out6 + rows_cap * 6; d.res_um_t = d.res_matches + 2 * mcap; d.res_um_d = d.res_um_t + T_ub + D;
         *res_len = (size_t)d.res_um_d + D + 1;
         *out_cap = rows_cap;
-        d.res = res_dev.p + res_off;
+        d.res = res_host + res_off;
 
         // ---- kernels (sizes come from device memory; the grids use the host-side upper bounds)
         const float *feats_dev = f.feats;
@@ -465,14 +465,13 @@ public:
             if (res_host) (void)hipHostFree(res_host);
             res_cap = res_total * 2;
             YDS_HIP(hipHostMalloc((void **)&res_host, res_cap * sizeof(int)));
-            res_dev.alloc(res_cap);
         }
         int T_ub = T_host;
         for (int b = 0; b < n_frames; ++b) {
             enqueue(frames[b], T_ub, in_off[b], res_off[b], &res_len[b], &out_cap[b]);
             T_ub += frames[b].D;
         }
-        YDS_HIP(hipMemcpyAsync(res_host, res_dev.p, res_total * sizeof(int), hipMemcpyDeviceToHost, stream));
+        // (the result blocks are in host memory already: a device-to-host copy command would queue behind frame uploads)
         YDS_HIP(hipStreamSynchronize(stream));
         for (int b = 0; b < n_frames; ++b) {
             const int *r = res_host + res_off[b];
@@ -560,7 +559,7 @@ public:
         }
     };
     DevBuf<float> mean, cov, gallery /* cosine: rows stored normalised */;
-    DevBuf<int> table, table_tmp, free_slots, track_lists, meta, in_dev, res_dev;
+    DevBuf<int> table, table_tmp, free_slots, track_lists, meta, in_dev;
     GrowBuf<float> feats_stage, feats_n, cost_dev;
     GrowBuf<int> det_lists;
     DevBuf<char> lsap_scratch;

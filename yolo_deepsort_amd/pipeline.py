@@ -58,6 +58,14 @@ class Pipeline:
         batch, h, w, _ = frames.shape
         _lib.check(_lib.load().yds_pipeline_prefetch_host(self._h, _lib.ptr(frames), h, w, batch))
 
+    def set_schedule(self, min_crops=None):
+        """Crops per batch from which the ReID pass is serialized with the detector passes (own stream otherwise);
+        -1 = always two streams, None = the library's policy.  Results do not depend on it."""
+        _lib.check(_lib.load().yds_pipeline_set_schedule(self._h, -2 if min_crops is None else int(min_crops)))
+
+    def last_schedule(self):
+        return "serialized" if _lib.load().yds_pipeline_last_schedule(self._h) else "two-stream"
+
     def stage_us(self):
         us = np.zeros(5, np.float32)
         _lib.check(_lib.load().yds_pipeline_stage_us(self._h, _lib.ptr(us)))
