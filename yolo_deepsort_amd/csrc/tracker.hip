@@ -13,7 +13,7 @@
 // single-workgroup kernels built from ordered compactions (ballot + prefix), so a frame is a fixed sequence of launches
 // whose sizes are read from device memory: the host synchronises ONCE per frame - or once per batch of frames
 // (step_batch, used by the pipeline) - to fetch the int32 rows.
-#include "tracker_dev.h"
+#include "tracker_lsap_dev.h"
 
 namespace yds {
 
@@ -50,14 +50,15 @@ enum Meta {
 struct TrkDev {
     TrackTable tab, tmp;
     int *meta, *free_slots;
-    float *mean, *cov, *gallery, *feats_n, *cost;
+    float *mean, *cov, *gallery, *feats_n, *cost, *cost_b;      // cost: appearance stage [Tc][D], cost_b: IOU stage [Tb][Db]
     const float *tlwh, *payload;                    // this frame's detections
     int *conf_idx, *unconf_idx, *rows, *cols, *flag_r, *flag_c, *rej;
     int *matches, *um_t_a, *um_t_keep, *um_t, *um_d, *um_d2, *iou_cand;
-    int *upd_slot, *upd_det, *upd_pos, *new_slot, *out_slot, *out_id;
+    int *upd_slot, *upd_det, *upd_pos, *upd_row, *upd_of, *upd_of_tmp, *new_slot, *out_id;
     float *out_payload;
     int budget, unbounded, n_init, max_age;
-    float max_dist, max_iou;
+    float max_dist, max_iou, flood_a, flood_b;      // thresholds of the two stages and the values their cost matrices are clamped to
+    int euclid;
     // per-frame result block (device copy of what goes back to the host): header, rows, debug lists
     int *res;
     int res_out6, res_matches, res_um_t, res_um_d;   // int offsets inside res
@@ -85,23 +86,50 @@ template <class Pred, class Emit> __device__ __forceinline__ int compact_ordered
     return total;
 }
 
-// Tracker.predict bookkeeping (track.py:110-123: age += 1, time_since_update += 1) and the confirmed / unconfirmed index
-// lists of Tracker._match (tracker.py:65-67), in list order.
-__global__ __launch_bounds__(256) void trk_begin_kernel(TrkDev d, int D) {
-    __shared__ int s_cnt[4];
-    const int T = d.meta[M_T];
-    for (int t = threadIdx.x; t < T; t += 256) { d.tab.age[t]++; d.tab.tsu[t]++; }
-    __syncthreads();
-    const int Tc = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] == CONFIRMED; }, [&](int t, int r) { d.conf_idx[r] = t; });
-    const int Tu = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] != CONFIRMED; }, [&](int t, int r) { d.unconf_idx[r] = t; });
-    if (threadIdx.x == 0) { d.meta[M_TC] = Tc; d.meta[M_D] = D; d.meta[M_TB] = Tu; }      // M_TB holds the unconfirmed count until stage A adds to it
+// -------------------------------------------------------------------------------------------- one frame = three launches
+// (round 4; rounds 1-3 ran ~14 launches per frame - begin, predict, cost, two LSAP forms, lists, IOU cost, two LSAP forms, lists,
+//  Kalman, gallery, output - and under a saturated GPU every single-workgroup launch waits for a CU to drain: 280 us per frame at
+//  30 persons inside the pipeline against 90 us on an idle chip)
+//   trk_front_kernel   (T x ceil(D / 16) workgroups)  appearance cost + gate of the confirmed tracks, on a LOCAL Kalman prediction
+//   trk_assoc_kernel   (one workgroup)                Tracker.predict for all tracks, both assignment problems with their list
+//                                                     bookkeeping, the IOU cost in between, Tracker.update on the integer table,
+//                                                     output selection, output rows of the tracks that were not updated
+//   trk_back_kernel    (one workgroup per match / new track)  Kalman update / initiate, gallery row, output row of updated tracks
+
+// deep_sort.py:73-87: state mean -> clipped corner box, int32 truncation, id, payload
+__device__ __forceinline__ void write_out_row(const float *m, int id, float payload, int *o) {
+    float w = m[2] * m[3], h = m[3];
+    float x = m[0] - w / 2.f, y = m[1] - h / 2.f;
+    float x2 = w + x, y2 = h + y;
+    x = fmaxf(x, 0.f); y = fmaxf(y, 0.f);
+    o[0] = (int)x; o[1] = (int)y; o[2] = (int)x2; o[3] = (int)y2; o[4] = id; o[5] = (int)payload;
 }
 
-__global__ void trk_predict_kernel(TrkDev d) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= d.meta[M_T]) return;
+// Appearance cost rows of the CONFIRMED tracks (tracker.py:56-78 gated_metric).  The state in memory is still the previous frame's
+// posterior: the block predicts its own track in registers (the same kf_predict_body the association kernel applies in place right
+// after this launch - same instruction sequence, same bits) and gates against that.  Row index = confirmed tracks in front of t in
+// list order (the position conf_idx will give it).
+__global__ __launch_bounds__(256) void trk_front_kernel(TrkDev d, int D) {
+    __shared__ float pm[8], pP[64];
+    const int t = blockIdx.x;
+    if (t >= d.meta[M_T] || d.tab.state[t] != CONFIRMED) return;
+    int row = 0;
+    for (int base = 0; base < t; base += 256) {
+        const int i = base + threadIdx.x;
+        row += __syncthreads_count(i < t && d.tab.state[i] == CONFIRMED);
+    }
     const int slot = d.tab.slot[t];
-    kf_predict_body(d.mean + (size_t)slot * 8, d.cov + (size_t)slot * 64);
+    if (threadIdx.x == 0) {
+        float m[8], P[64];
+        for (int i = 0; i < 8; ++i) m[i] = d.mean[(size_t)slot * 8 + i];
+        for (int i = 0; i < 64; ++i) P[i] = d.cov[(size_t)slot * 64 + i];
+        kf_predict_body(m, P);
+        for (int i = 0; i < 8; ++i) pm[i] = m[i];
+        for (int i = 0; i < 64; ++i) pP[i] = P[i];
+    }
+    __syncthreads();
+    appearance_cost_block(d.gallery, slot, d.tab.n_feat[t], d.budget, d.feats_n, D, blockIdx.y * 16, pm, pP, d.tlwh, d.max_dist, d.flood_a, 1, d.euclid,
+                          d.cost + (size_t)row * D);
 }
 
 // min_cost_matching list bookkeeping (linear_assignment.py:58-72) for one solved assignment problem:
@@ -109,8 +137,9 @@ __global__ void trk_predict_kernel(TrkDev d) {
 //   matches in row order; a pair is rejected when cost[row, col] > max_distance.
 // row_name(r) / col_name(c) translate problem rows / columns to track indices / detection indices.
 template <class RowName, class ColName>
-__device__ __forceinline__ void assign_lists(const TrkDev &d, int *s_cnt, int nr, int nc, int n_pairs, float max_distance, RowName row_name,
-                                             ColName col_name, int *matches, int &n_matches, int *um_t, int &n_um_t, int *um_d, int &n_um_d) {
+__device__ __forceinline__ void assign_lists(const TrkDev &d, const float *cost, int *s_cnt, int nr, int nc, int n_pairs, float max_distance,
+                                             RowName row_name, ColName col_name, int *matches, int &n_matches, int *um_t, int &n_um_t, int *um_d,
+                                             int &n_um_d) {
     const int tid = threadIdx.x;
     for (int r = tid; r < nr; r += 256) d.flag_r[r] = 0;
     for (int c = tid; c < nc; c += 256) d.flag_c[c] = 0;
@@ -119,7 +148,7 @@ __device__ __forceinline__ void assign_lists(const TrkDev &d, int *s_cnt, int nr
         const int r = d.rows[k], c = d.cols[k];
         d.flag_r[r] = 1;
         d.flag_c[c] = 1;
-        d.rej[k] = d.cost[(size_t)r * nc + c] > max_distance ? 1 : 0;
+        d.rej[k] = cost[(size_t)r * nc + c] > max_distance ? 1 : 0;
     }
     __syncthreads();
     const int d1 = compact_ordered(nc, s_cnt, [&](int c) { return d.flag_c[c] == 0; }, [&](int c, int q) { um_d[q] = col_name(c); });
@@ -133,41 +162,59 @@ __device__ __forceinline__ void assign_lists(const TrkDev &d, int *s_cnt, int nr
     n_matches += nm;
 }
 
-// after the appearance-stage assignment: its lists, then the IOU-stage candidates (tracker.py:80-85):
-// unconfirmed tracks (index order) + unmatched confirmed tracks with time_since_update == 1
-__global__ __launch_bounds__(256) void trk_match_a_kernel(TrkDev d) {
+// The sequential part of a frame on ONE workgroup (every step consumes the lists of the one before; sizes live in registers):
+//   Tracker.predict (track.py:110-123 + kalman_filter.py:89-124) for every track, confirmed / unconfirmed index lists (tracker.py:65-67)
+//   stage A: linear assignment on the appearance cost (trk_front_kernel) + its lists, IOU-stage candidates (tracker.py:80-85)
+//   stage B: IOU cost (iou_matching.py:46-91) + linear assignment + lists
+//   Tracker.update on the integer table (tracker.py:129-176), deleted tracks dropped, output selection (deep_sort.py:67-71)
+// smem_bytes of dynamic LDS belong to the assignment solvers (tracker_lsap_dev.h); lsap_state: global scratch for problems whose
+// solver state exceeds the LDS (nullptr when the host-side bounds rule that out).
+__global__ __launch_bounds__(256) void trk_assoc_kernel(TrkDev d, int D, char *lsap_state, int smem_bytes) {
     __shared__ int s_cnt[4];
-    const int Tc = d.meta[M_TC], D = d.meta[M_D], Tu = d.meta[M_TB];
-    const int n_pairs = (Tc > 0 && D > 0) ? d.meta[M_NA] : 0;              // either side empty: nothing was solved (linear_assignment.py:48-49)
-    int n_matches = 0, n_um_t = 0, n_um_d = 0;
-    assign_lists(d, s_cnt, Tc, D, n_pairs, d.max_dist, [&](int r) { return d.conf_idx[r]; }, [&](int c) { return c; }, d.matches, n_matches,
-                 d.um_t_a, n_um_t, d.um_d, n_um_d);
-    __syncthreads();
-    for (int q = threadIdx.x; q < Tu; q += 256) d.iou_cand[q] = d.unconf_idx[q];
-    const int c1 = compact_ordered(n_um_t, s_cnt, [&](int q) { return d.tab.tsu[d.um_t_a[q]] == 1; }, [&](int q, int r) { d.iou_cand[Tu + r] = d.um_t_a[q]; });
-    const int k1 = compact_ordered(n_um_t, s_cnt, [&](int q) { return d.tab.tsu[d.um_t_a[q]] != 1; }, [&](int q, int r) { d.um_t_keep[r] = d.um_t_a[q]; });
-    if (threadIdx.x == 0) {
-        d.meta[M_NM_A] = n_matches; d.meta[M_NUT_A] = n_um_t; d.meta[M_NKEEP] = k1;
-        d.meta[M_TB] = Tu + c1; d.meta[M_DB] = n_um_d;
-    }
-}
-
-// after the IOU-stage assignment: final lists, Tracker.update (tracker.py:129-176: Track.update / mark_missed /
-// _initiate_track, deleted tracks dropped) on the integer table, the lists the Kalman / gallery kernels consume,
-// and the output selection of DeepSort.update (deep_sort.py:67-71).
-__global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
-    __shared__ int s_cnt[4];
+    __shared__ int s_maxfeat;
     const int tid = threadIdx.x;
-    const int Tb = d.meta[M_TB], Db = d.meta[M_DB], k_keep = d.meta[M_NKEEP];
-    const int n_pairs = (Tb > 0 && Db > 0) ? d.meta[M_NB] : 0;
-    int n_matches = d.meta[M_NM_A], n_um_t_b = 0, n_um_d = 0;
-    int *um_t_b = d.um_t + k_keep;                                  // final unmatched tracks = [kept from stage A] + [stage B]
-    assign_lists(d, s_cnt, Tb, Db, n_pairs, d.max_iou, [&](int r) { return d.iou_cand[r]; }, [&](int c) { return d.um_d[c]; }, d.matches, n_matches,
-                 um_t_b, n_um_t_b, d.um_d2, n_um_d);
-    for (int q = tid; q < k_keep; q += 256) d.um_t[q] = d.um_t_keep[q];
-    __syncthreads();
-    const int M = n_matches, n_um_t = k_keep + n_um_t_b, Nn = n_um_d;
     int T = d.meta[M_T];
+    for (int t = tid; t < T; t += 256) {
+        d.tab.age[t]++; d.tab.tsu[t]++;
+        const int slot = d.tab.slot[t];
+        kf_predict_body(d.mean + (size_t)slot * 8, d.cov + (size_t)slot * 64);
+    }
+    __syncthreads();
+    const int Tc = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] == CONFIRMED; }, [&](int t, int r) { d.conf_idx[r] = t; });
+    const int Tu = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] != CONFIRMED; }, [&](int t, int r) { d.unconf_idx[r] = t; });
+    __syncthreads();
+    // ---- stage A (either side empty: nothing is solved, linear_assignment.py:48-49)
+    lsap_solve_block(d.cost, Tc, D, d.rows, d.cols, d.meta + M_NA, lsap_state, smem_bytes);
+    const int n_pairs_a = (Tc > 0 && D > 0) ? d.meta[M_NA] : 0;
+    int n_matches = 0, n_um_t_a = 0, n_um_d_a = 0;
+    assign_lists(d, d.cost, s_cnt, Tc, D, n_pairs_a, d.max_dist, [&](int r) { return d.conf_idx[r]; }, [&](int c) { return c; }, d.matches, n_matches,
+                 d.um_t_a, n_um_t_a, d.um_d, n_um_d_a);
+    __syncthreads();
+    // IOU-stage candidates: unconfirmed tracks (index order) + unmatched confirmed tracks with time_since_update == 1
+    for (int q = tid; q < Tu; q += 256) d.iou_cand[q] = d.unconf_idx[q];
+    const int c1 = compact_ordered(n_um_t_a, s_cnt, [&](int q) { return d.tab.tsu[d.um_t_a[q]] == 1; }, [&](int q, int r) { d.iou_cand[Tu + r] = d.um_t_a[q]; });
+    const int k_keep = compact_ordered(n_um_t_a, s_cnt, [&](int q) { return d.tab.tsu[d.um_t_a[q]] != 1; }, [&](int q, int r) { d.um_t_keep[r] = d.um_t_a[q]; });
+    const int n_matches_a = n_matches;
+    const int Tb = Tu + c1, Db = n_um_d_a;
+    __syncthreads();
+    // ---- stage B
+    for (int idx = tid; idx < Tb * Db; idx += 256) {
+        const int r = idx / Db, c = idx - r * Db, t = d.iou_cand[r];
+        d.cost_b[idx] = iou_cost_entry(d.mean + (size_t)d.tab.slot[t] * 8, d.tlwh + (size_t)d.um_d[c] * 4, d.tab.tsu[t] > 1, d.max_iou, d.flood_b);
+    }
+    __syncthreads();
+    lsap_solve_block(d.cost_b, Tb, Db, d.rows, d.cols, d.meta + M_NB, lsap_state, smem_bytes);
+    const int n_pairs_b = (Tb > 0 && Db > 0) ? d.meta[M_NB] : 0;
+    int n_um_t_b = 0, n_um_d = 0;
+    int *um_t_b = d.um_t + k_keep;                                  // final unmatched tracks = [kept from stage A] + [stage B]
+    assign_lists(d, d.cost_b, s_cnt, Tb, Db, n_pairs_b, d.max_iou, [&](int r) { return d.iou_cand[r]; }, [&](int c) { return d.um_d[c]; }, d.matches,
+                 n_matches, um_t_b, n_um_t_b, d.um_d2, n_um_d);
+    for (int q = tid; q < k_keep; q += 256) d.um_t[q] = d.um_t_keep[q];
+    const int M = n_matches, n_um_t = k_keep + n_um_t_b, Nn = n_um_d;
+    // entry k of the update list is handled by workgroup k of trk_back_kernel; upd_of[t] / upd_row[k] connect it with the output row
+    for (int t = tid; t < T + Nn; t += 256) d.upd_of[t] = -1;
+    for (int k = tid; k < M + Nn; k += 256) d.upd_row[k] = -1;
+    __syncthreads();
     // ---- Track.update (track.py:125-144) for every match
     for (int k = tid; k < M; k += 256) {
         const int t = d.matches[2 * k], det = d.matches[2 * k + 1];
@@ -183,6 +230,7 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
         if (d.tab.state[t] == TENTATIVE && hits >= d.n_init) d.tab.state[t] = CONFIRMED;
         d.tab.payload[t] = d.payload[det];
         d.upd_slot[k] = d.tab.slot[t]; d.upd_det[k] = det; d.upd_pos[k] = pos;
+        d.upd_of[t] = k;
     }
     // ---- Track.mark_missed (track.py:146-152)
     for (int q = tid; q < n_um_t; q += 256) {
@@ -198,7 +246,7 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
         d.tab.n_feat[t] = 1; d.tab.head[t] = 1 % d.budget;
         d.tab.payload[t] = d.payload[det];
         d.new_slot[k] = slot;
-        // the feature / Kalman kernels take one combined list: entries [M, M + Nn) are the new tracks
+        // the back kernel takes one combined list: entries [M, M + Nn) are the new tracks
         d.upd_slot[M + k] = slot; d.upd_det[M + k] = det; d.upd_pos[M + k] = 0;
     }
     __syncthreads();
@@ -207,6 +255,7 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
     const int alive = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] != DELETED; }, [&](int t, int r) {
         d.tmp.slot[r] = d.tab.slot[t]; d.tmp.id[r] = d.tab.id[t]; d.tmp.hits[r] = d.tab.hits[t]; d.tmp.age[r] = d.tab.age[t]; d.tmp.tsu[r] = d.tab.tsu[t];
         d.tmp.state[r] = d.tab.state[t]; d.tmp.n_feat[r] = d.tab.n_feat[t]; d.tmp.head[r] = d.tab.head[t]; d.tmp.payload[r] = d.tab.payload[t];
+        d.upd_of_tmp[r] = d.upd_of[t];
     });
     const int freed = compact_ordered(T, s_cnt, [&](int t) { return d.tab.state[t] == DELETED; },
                                       [&](int t, int r) { d.free_slots[n_free - Nn + r] = d.tab.slot[t]; });
@@ -214,13 +263,20 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
     for (int t = tid; t < alive; t += 256) {
         d.tab.slot[t] = d.tmp.slot[t]; d.tab.id[t] = d.tmp.id[t]; d.tab.hits[t] = d.tmp.hits[t]; d.tab.age[t] = d.tmp.age[t]; d.tab.tsu[t] = d.tmp.tsu[t];
         d.tab.state[t] = d.tmp.state[t]; d.tab.n_feat[t] = d.tmp.n_feat[t]; d.tab.head[t] = d.tmp.head[t]; d.tab.payload[t] = d.tmp.payload[t];
+        d.upd_of[t] = d.upd_of_tmp[t];
     }
     __syncthreads();
-    // ---- output selection (deep_sort.py:67-71): confirmed and time_since_update <= 1, in list order
-    const int n_out = compact_ordered(alive, s_cnt, [&](int t) { return d.tab.state[t] == CONFIRMED && d.tab.tsu[t] <= 1; },
-                                      [&](int t, int r) { d.out_slot[r] = d.tab.slot[t]; d.out_id[r] = d.tab.id[t]; d.out_payload[r] = d.tab.payload[t]; });
+    // ---- output selection (deep_sort.py:67-71): confirmed and time_since_update <= 1, in list order.  A selected track that was
+    //      updated in this frame gets its row from the workgroup that runs its Kalman update (trk_back_kernel); the others keep
+    //      their predicted state, which this kernel wrote: their rows are final here.
+    const int n_out = compact_ordered(alive, s_cnt, [&](int t) { return d.tab.state[t] == CONFIRMED && d.tab.tsu[t] <= 1; }, [&](int t, int r) {
+        const int slot = d.tab.slot[t], id = d.tab.id[t], k = d.upd_of[t];
+        const float payload = d.tab.payload[t];
+        d.out_id[r] = id; d.out_payload[r] = payload;
+        if (k >= 0) d.upd_row[k] = r;
+        else write_out_row(d.mean + (size_t)slot * 8, id, payload, d.res + d.res_out6 + r * 6);
+    });
     // ---- largest gallery of a live track: the host grows unbounded galleries by what is really held, not by frames seen
-    __shared__ int s_maxfeat;
     if (tid == 0) s_maxfeat = 0;
     __syncthreads();
     {
@@ -234,6 +290,8 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
     for (int q = tid; q < n_um_t; q += 256) d.res[d.res_um_t + q] = d.um_t[q];
     for (int q = tid; q < Nn; q += 256) d.res[d.res_um_d + q] = d.um_d2[q];
     if (tid == 0) {
+        d.meta[M_TC] = Tc; d.meta[M_D] = D; d.meta[M_TB] = Tb; d.meta[M_DB] = Db;
+        d.meta[M_NM_A] = n_matches_a; d.meta[M_NUT_A] = n_um_t_a; d.meta[M_NKEEP] = k_keep;
         d.meta[M_T] = alive; d.meta[M_NEXT_ID] = next_id + Nn; d.meta[M_NFREE] = n_free - Nn + freed;
         d.meta[M_NM] = M; d.meta[M_NUT] = n_um_t; d.meta[M_NUD] = Nn; d.meta[M_NOUT] = n_out;
         d.meta[M_MAXFEAT] = s_maxfeat;
@@ -241,41 +299,30 @@ __global__ __launch_bounds__(256) void trk_match_b_kernel(TrkDev d) {
     }
 }
 
-// KalmanFilter.update for the matches (kalman_filter.py:161-204 via tracker.py:143-150), initiate for the new tracks
-// (:54-87), and the gallery rows of both (tracker.py:165-176 + nn_matching.py:152-155)
-__global__ void trk_kalman_kernel(TrkDev d) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// Workgroup k: entry k of the update list - KalmanFilter.update for a match (kalman_filter.py:161-204 via tracker.py:143-150) or
+// initiate for a new track (:54-87) on one thread, the gallery row (tracker.py:165-176 + nn_matching.py:152-155) on all of them,
+// and the output row when the track is among the selected ones (deep_sort.py:73-87)
+__global__ __launch_bounds__(128) void trk_back_kernel(TrkDev d) {
+    const int k = blockIdx.x;
     const int M = d.meta[M_NM], Nn = d.meta[M_NUD];
     if (k >= M + Nn) return;
-    const int slot = d.upd_slot[k];
-    const float *b = d.tlwh + (size_t)d.upd_det[k] * 4;
-    float *m = d.mean + (size_t)slot * 8, *P = d.cov + (size_t)slot * 64;
-    if (k < M) {
-        float z[4];
-        to_xyah(b, z);
-        kf_update_body(m, P, z);
-    } else {
-        kf_initiate_body(m, P, b);
+    const int slot = d.upd_slot[k], det = d.upd_det[k];
+    if (threadIdx.x == 0) {
+        const float *b = d.tlwh + (size_t)det * 4;
+        float *m = d.mean + (size_t)slot * 8, *P = d.cov + (size_t)slot * 64;
+        if (k < M) {
+            float z[4];
+            to_xyah(b, z);
+            kf_update_body(m, P, z);
+        } else {
+            kf_initiate_body(m, P, b);
+        }
+        const int r = d.upd_row[k];
+        if (r >= 0) write_out_row(m, d.out_id[r], d.out_payload[r], d.res + d.res_out6 + r * 6);
     }
-}
-__global__ void trk_append_kernel(TrkDev d) {
-    const int k = blockIdx.x;
-    if (k >= d.meta[M_NM] + d.meta[M_NUD]) return;
-    float *dst = d.gallery + ((size_t)d.upd_slot[k] * d.budget + d.upd_pos[k]) * EMB;
-    const float *src = d.feats_n + (size_t)d.upd_det[k] * EMB;
-    for (int c = threadIdx.x; c < EMB; c += blockDim.x) dst[c] = src[c];
-}
-// deep_sort.py:73-87 on the selected tracks -> int32 rows in the result block
-__global__ void trk_output_kernel(TrkDev d) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= d.meta[M_NOUT]) return;
-    const float *m = d.mean + (size_t)d.out_slot[t] * 8;
-    float w = m[2] * m[3], h = m[3];
-    float x = m[0] - w / 2.f, y = m[1] - h / 2.f;
-    float x2 = w + x, y2 = h + y;
-    x = fmaxf(x, 0.f); y = fmaxf(y, 0.f);
-    int *o = d.res + d.res_out6 + t * 6;
-    o[0] = (int)x; o[1] = (int)y; o[2] = (int)x2; o[3] = (int)y2; o[4] = d.out_id[t]; o[5] = (int)d.out_payload[t];
+    float *dst = d.gallery + ((size_t)slot * d.budget + d.upd_pos[k]) * EMB;
+    const float *src = d.feats_n + (size_t)det * EMB;
+    for (int c = threadIdx.x; c < EMB; c += 128) dst[c] = src[c];
 }
 
 // ============================================================================================ host
@@ -314,7 +361,7 @@ public:
     void grow(int cap) {
         YDS_HIP(hipStreamSynchronize(stream));
         DevBuf<float> m((size_t)cap * 8), c((size_t)cap * 64), g((size_t)cap * budget * EMB);
-        DevBuf<int> tab((size_t)cap * TAB_FIELDS), tmp((size_t)cap * TAB_FIELDS), fs(cap), lists((size_t)cap * 12);
+        DevBuf<int> tab((size_t)cap * TAB_FIELDS), tmp((size_t)cap * TAB_FIELDS), fs(cap), lists((size_t)cap * 13);
         if (capacity) {
             YDS_HIP(hipMemcpy(m.p, mean.p, (size_t)capacity * 8 * 4, hipMemcpyDeviceToDevice));
             YDS_HIP(hipMemcpy(c.p, cov.p, (size_t)capacity * 64 * 4, hipMemcpyDeviceToDevice));
@@ -352,73 +399,75 @@ public:
 
     struct FrameIn { const float *tlwh; const float *feats; bool feats_on_device; const int *feat_rows; const float *payload; int D; };
 
-    // Enqueues one frame; T_ub = host-side upper bound of the live track count when it starts.  Returns the int offset of
-    // this frame's result block inside res_host (pinned host memory the kernels store into: no copy command at the end).
-    size_t enqueue(const FrameIn &f, int T_ub, size_t in_off, size_t res_off, size_t *res_len, int *out_cap) {
+    // Enqueues one frame (three launches, see the kernels); T_ub = host-side upper bound of the live track count when it starts.
+    // feats_n_frame: this frame's normalised embeddings when the caller has normalised the whole batch in one launch, else nullptr.
+    // Returns the int offset of this frame's result block inside res_host (pinned host memory the kernels store into: no copy
+    // command at the end).
+    size_t enqueue(const FrameIn &f, int T_ub, size_t in_off, size_t res_off, size_t *res_len, int *out_cap, float *feats_n_frame) {
         const int D = f.D, Dn = std::max(D, 1), Tn = std::max(T_ub, 1);
         // ---- inputs: tlwh, payload (and feat_rows) were packed into in_host by the caller; one H2D per batch
         TrkDev d;
         d.tab = table_at(table.p, capacity); d.tmp = table_at(table_tmp.p, capacity);
         d.meta = meta.p; d.free_slots = free_slots.p;
         d.mean = mean.p; d.cov = cov.p; d.gallery = gallery.p;
-        feats_n.ensure_keep((size_t)Dn * EMB);
-        cost_dev.ensure_keep((size_t)(Tn + Dn) * Dn);
+        if (!feats_n_frame) feats_n.ensure_keep((size_t)Dn * EMB);
+        const size_t cost_n = (size_t)(Tn + Dn) * Dn;
+        cost_dev.ensure_keep(2 * cost_n);
         det_lists.ensure_keep((size_t)Dn * 8 + (size_t)(Tn + Dn) * 8);
-        d.feats_n = feats_n.p; d.cost = cost_dev.p;
+        d.feats_n = feats_n_frame ? feats_n_frame : feats_n.p;
+        d.cost = cost_dev.p; d.cost_b = cost_dev.p + cost_n;
         d.tlwh = reinterpret_cast<const float *>(in_dev.p + in_off);
         d.payload = d.tlwh + (size_t)D * 4;
         const int *feat_rows_dev = f.feat_rows ? reinterpret_cast<const int *>(d.payload + D) : nullptr;
-        int *tl = track_lists.p;                                  // 12 lists of `capacity` ints
+        int *tl = track_lists.p;                                  // 13 lists of `capacity` ints
         const int cap = capacity;
         d.conf_idx = tl; d.unconf_idx = tl + cap; d.flag_r = tl + 2 * cap; d.um_t_a = tl + 3 * cap; d.um_t_keep = tl + 4 * cap; d.um_t = tl + 5 * cap;
-        d.iou_cand = tl + 6 * cap; d.out_slot = tl + 7 * cap; d.out_id = tl + 8 * cap; d.out_payload = reinterpret_cast<float *>(tl + 9 * cap);
-        d.rows = tl + 10 * cap; d.cols = tl + 11 * cap;
+        d.iou_cand = tl + 6 * cap; d.upd_of = tl + 7 * cap; d.out_id = tl + 8 * cap; d.out_payload = reinterpret_cast<float *>(tl + 9 * cap);
+        d.rows = tl + 10 * cap; d.cols = tl + 11 * cap; d.upd_of_tmp = tl + 12 * cap;
         int *dl = det_lists.p;                                    // per-detection lists (D) and per-(track+det) lists
         d.flag_c = dl; d.um_d = dl + Dn; d.um_d2 = dl + 2 * Dn; d.new_slot = dl + 3 * Dn; d.rej = dl + 4 * Dn;
         int *pl = dl + 8 * (size_t)Dn;
         const int P = Tn + Dn;
-        d.matches = pl; d.upd_slot = pl + 2 * P; d.upd_det = pl + 3 * P; d.upd_pos = pl + 4 * P;
+        d.matches = pl; d.upd_slot = pl + 2 * P; d.upd_det = pl + 3 * P; d.upd_pos = pl + 4 * P; d.upd_row = pl + 5 * P;
         d.budget = budget; d.unbounded = unbounded ? 1 : 0; d.n_init = n_init; d.max_age = max_age;
         d.max_dist = (float)max_dist; d.max_iou = (float)max_iou;
+        d.flood_a = (float)(max_dist + 1e-5); d.flood_b = (float)(max_iou + 1e-5);           // linear_assignment.py:52
+        d.euclid = metric == METRIC_EUCLIDEAN ? 1 : 0;
         // ---- result block layout: header | out6 rows | matches | unmatched tracks | unmatched detections
-        const int rows_cap = T_ub + D, mcap = std::min(T_ub + D, T_ub + D);
+        const int rows_cap = T_ub + D, mcap = T_ub + D;
         d.res_out6 = M_COUNT; d.res_matches = d.res_out6 + rows_cap * 6; d.res_um_t = d.res_matches + 2 * mcap; d.res_um_d = d.res_um_t + T_ub + D;
         *res_len = (size_t)d.res_um_d + D + 1;
         *out_cap = rows_cap;
         d.res = res_host + res_off;
 
         // ---- kernels (sizes come from device memory; the grids use the host-side upper bounds)
-        const float *feats_dev = f.feats;
-        if (!f.feats_on_device && D) {
-            int n_rows = D;
-            if (f.feat_rows) for (int k = 0; k < D; ++k) n_rows = std::max(n_rows, f.feat_rows[k] + 1);
-            feats_stage.ensure_keep((size_t)n_rows * EMB);
-            YDS_HIP(hipMemcpyAsync(feats_stage.p, f.feats, (size_t)n_rows * EMB * 4, hipMemcpyHostToDevice, stream));
-            feats_dev = feats_stage.p;
+        if (!feats_n_frame && D) {
+            const float *feats_dev = f.feats;
+            if (!f.feats_on_device) {
+                int n_rows = D;
+                if (f.feat_rows) for (int k = 0; k < D; ++k) n_rows = std::max(n_rows, f.feat_rows[k] + 1);
+                feats_stage.ensure_keep((size_t)n_rows * EMB);
+                YDS_HIP(hipMemcpyAsync(feats_stage.p, f.feats, (size_t)n_rows * EMB * 4, hipMemcpyHostToDevice, stream));
+                feats_dev = feats_stage.p;
+            }
+            hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, stream, feats_dev, feat_rows_dev, feats_n.p, D,
+                               metric == METRIC_COSINE ? 1 : 0);     // x / ||x|| once per frame (nn_matching.py:50-52); euclidean: as is
         }
-        if (D) hipLaunchKernelGGL(normalize_rows_kernel, dim3((D + 3) / 4), dim3(256), 0, stream, feats_dev, feat_rows_dev, feats_n.p, D,
-                                  metric == METRIC_COSINE ? 1 : 0);     // x / ||x|| once per frame (nn_matching.py:50-52); euclidean: as is
-        hipLaunchKernelGGL(trk_begin_kernel, dim3(1), dim3(256), 0, stream, d, D);
-        if (T_ub) hipLaunchKernelGGL(trk_predict_kernel, dim3((T_ub + 63) / 64), dim3(64), 0, stream, d);
-        if (T_ub && D) {
-            hipLaunchKernelGGL(appearance_cost_kernel, dim3(T_ub, (D + 15) / 16), dim3(256), 0, stream, gallery.p, (const int *)nullptr,
-                               (const int *)nullptr, budget, feats_n.p, D, mean.p, cov.p, d.tlwh, (float)max_dist, (float)(max_dist + 1e-5), 1,
-                               metric == METRIC_EUCLIDEAN ? 1 : 0, cost_dev.p, d.conf_idx, d.tab.slot, d.tab.n_feat, meta.p + M_TC);
-            launch_lsap(cost_dev.p, T_ub, D, meta.p + M_TC, d.rows, d.cols, meta.p + M_NA, lsap_scratch, stream);
+        if (T_ub && D) hipLaunchKernelGGL(trk_front_kernel, dim3(T_ub, (D + 15) / 16), dim3(256), 0, stream, d, D);
+        // the assignment solvers get the whole LDS; their state moves to a global scratch when even that is too small (~3000 rows)
+        static bool attr_set = false;
+        if (!attr_set) {
+            YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(trk_assoc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LSAP_LDS_MAX));
+            attr_set = true;
         }
-        hipLaunchKernelGGL(trk_match_a_kernel, dim3(1), dim3(256), 0, stream, d);
-        if (T_ub && D) {
-            hipLaunchKernelGGL(iou_cost_kernel, dim3(((size_t)T_ub * D + 255) / 256), dim3(256), 0, stream, mean.p, (const int *)nullptr,
-                               (const int *)nullptr, 0, d.tlwh, d.um_d, 0, (float)max_iou, (float)(max_iou + 1e-5), cost_dev.p, meta.p + M_TB,
-                               d.iou_cand, d.tab.slot, d.tab.tsu);
-            launch_lsap(cost_dev.p, T_ub, D, meta.p + M_TB, d.rows, d.cols, meta.p + M_NB, lsap_scratch, stream);
+        const size_t lsap_state = (size_t)std::max(Tn, Dn) * LSAP_STATE_BYTES;
+        if (lsap_state > LSAP_LDS_MAX && lsap_scratch.n < lsap_state) {
+            YDS_HIP(hipStreamSynchronize(stream));                   // nothing may still use the old scratch
+            lsap_scratch.alloc(lsap_state);
         }
-        hipLaunchKernelGGL(trk_match_b_kernel, dim3(1), dim3(256), 0, stream, d);
-        if (D) {
-            hipLaunchKernelGGL(trk_kalman_kernel, dim3((D + 63) / 64), dim3(64), 0, stream, d);
-            hipLaunchKernelGGL(trk_append_kernel, dim3(D), dim3(128), 0, stream, d);
-        }
-        if (rows_cap) hipLaunchKernelGGL(trk_output_kernel, dim3((rows_cap + 63) / 64), dim3(64), 0, stream, d);
+        hipLaunchKernelGGL(trk_assoc_kernel, dim3(1), dim3(256), LSAP_LDS_MAX, stream, d, D, lsap_state > LSAP_LDS_MAX ? lsap_scratch.p : (char *)nullptr,
+                           (int)LSAP_LDS_MAX);
+        if (D) hipLaunchKernelGGL(trk_back_kernel, dim3(D), dim3(128), 0, stream, d);
         YDS_HIP(hipGetLastError());
         return res_off;
     }
@@ -466,9 +515,34 @@ public:
             res_cap = res_total * 2;
             YDS_HIP(hipHostMalloc((void **)&res_host, res_cap * sizeof(int)));
         }
+        // ---- embeddings of the whole batch normalised in ONE launch when they already sit back to back on the device (the
+        //      pipeline's ReID pass writes them that way): x / ||x|| once per frame in the reference (nn_matching.py:50-52)
+        bool batch_norm = n_frames > 1 && D_sum > 0;
+        {
+            const float *expect = nullptr;
+            for (int b = 0; b < n_frames && batch_norm; ++b) {
+                const FrameIn &f = frames[b];
+                if (!f.D) continue;
+                if (!f.feats_on_device || f.feat_rows || (expect && f.feats != expect)) batch_norm = false;
+                expect = f.feats + (size_t)f.D * EMB;
+            }
+        }
+        std::vector<float *> fn(n_frames, nullptr);
+        if (batch_norm) {
+            feats_n.ensure_keep((size_t)D_sum * EMB);
+            const float *first_feats = nullptr;
+            size_t off = 0;
+            for (int b = 0; b < n_frames; ++b) {
+                if (frames[b].D && !first_feats) first_feats = frames[b].feats;
+                fn[b] = feats_n.p + off * EMB;
+                off += frames[b].D;
+            }
+            hipLaunchKernelGGL(normalize_rows_kernel, dim3((D_sum + 3) / 4), dim3(256), 0, stream, first_feats, (const int *)nullptr, feats_n.p, D_sum,
+                               metric == METRIC_COSINE ? 1 : 0);
+        }
         int T_ub = T_host;
         for (int b = 0; b < n_frames; ++b) {
-            enqueue(frames[b], T_ub, in_off[b], res_off[b], &res_len[b], &out_cap[b]);
+            enqueue(frames[b], T_ub, in_off[b], res_off[b], &res_len[b], &out_cap[b], fn[b]);
             T_ub += frames[b].D;
         }
         // (the result blocks are in host memory already: a device-to-host copy command would queue behind frame uploads)

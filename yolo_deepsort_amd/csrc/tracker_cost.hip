@@ -30,57 +30,11 @@ __global__ __launch_bounds__(256) void appearance_cost_kernel(const float *galle
                                                              const float *feats_n, int D, const float *mean, const float *cov,
                                                              const float *tlwh, float max_dist, float flood, int do_gate, int euclid, float *cost,
                                                              const int *idx, const int *tab_slot, const int *tab_nfeat, const int *count_p) {
-    __shared__ float fs[16][EMB + 1], gs[16][EMB + 1];
-    __shared__ float best[16][17];
-    const int t = blockIdx.x, d0 = blockIdx.y * 16;
+    const int t = blockIdx.x;
     if (count_p && t >= *count_p) return;
-    const int nd = min(16, D - d0);
     const int slot = idx ? tab_slot[idx[t]] : slots[t], rows = idx ? tab_nfeat[idx[t]] : n_rows[t];
-    for (int i = threadIdx.x; i < 16 * (EMB / 4); i += blockDim.x) {        // detection slab, float4 coalesced
-        const int d = i / (EMB / 4), k4 = i % (EMB / 4);
-        float4 v = d < nd ? *reinterpret_cast<const float4 *>(feats_n + (size_t)(d0 + d) * EMB + k4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        fs[d][k4 * 4] = v.x; fs[d][k4 * 4 + 1] = v.y; fs[d][k4 * 4 + 2] = v.z; fs[d][k4 * 4 + 3] = v.w;
-    }
-    const int r = threadIdx.x >> 4, d = threadIdx.x & 15;
-    float run_min = INFINITY;
-    for (int g0 = 0; g0 < rows; g0 += 16) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 16 * (EMB / 4); i += blockDim.x) {
-            const int g = i / (EMB / 4), k4 = i % (EMB / 4);
-            float4 v = g0 + g < rows ? *reinterpret_cast<const float4 *>(gallery_n + ((size_t)slot * budget + g0 + g) * EMB + k4 * 4)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-            gs[g][k4 * 4] = v.x; gs[g][k4 * 4 + 1] = v.y; gs[g][k4 * 4 + 2] = v.z; gs[g][k4 * 4 + 3] = v.w;
-        }
-        __syncthreads();
-        if (g0 + r < rows) {
-            float dot = 0.f;
-            if (euclid) {                                        // _pdist nn_matching.py:4-27: sum (a - b)^2
-#pragma unroll 8
-                for (int k = 0; k < EMB; ++k) { const float df = gs[r][k] - fs[d][k]; dot += df * df; }
-                run_min = fminf(run_min, dot);
-            } else {
-#pragma unroll 8
-                for (int k = 0; k < EMB; ++k) dot += gs[r][k] * fs[d][k];
-                run_min = fminf(run_min, 1.f - dot);
-            }
-        }
-    }
-    best[r][d] = run_min;
-    __syncthreads();
-    if ((int)threadIdx.x < nd) {
-        float c = INFINITY;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) c = fminf(c, best[q][threadIdx.x]);
-        if (euclid) c = fmaxf(c, 0.f);                           // torch.clamp(min=0) nn_matching.py:74
-        const int dd = d0 + threadIdx.x;
-        if (do_gate) {
-            float z[4];
-            to_xyah(tlwh + (size_t)dd * 4, z);
-            if (gate2(mean + (size_t)slot * 8, cov + (size_t)slot * 64, z) > CHI2_2DOF) c = INFTY_COST;
-        }
-        if (max_dist > 0.f && c > max_dist) c = flood;            // linear_assignment.py:52
-        cost[(size_t)t * D + dd] = c;
-    }
+    appearance_cost_block(gallery_n, slot, rows, budget, feats_n, D, blockIdx.y * 16, mean + (size_t)slot * 8, cov + (size_t)slot * 64, tlwh, max_dist,
+                          flood, do_gate, euclid, cost + (size_t)t * D);
 }
 
 // ------------------------------------------------------------------------------------------ IOU cost
@@ -93,17 +47,8 @@ __global__ void iou_cost_kernel(const float *mean, const int *slots, const int *
     if (idx >= T * D) return;
     int t = idx / D, d = idx - t * D;
     const float *m = mean + (size_t)(cand ? tab_slot[cand[t]] : slots[t]) * 8;
-    float bw = m[2] * m[3], bh = m[3];                        // Track.to_tlwh track.py:81-94
-    float bx = m[0] - bw / 2.f, by = m[1] - bh / 2.f;
-    const float *c = tlwh + (size_t)det_idx[d] * 4;
-    float ix0 = fmaxf(bx, c[0]), iy0 = fmaxf(by, c[1]);
-    float ix1 = fminf(bx + bw, c[2] + c[0]), iy1 = fminf(by + bh, c[3] + c[1]);
-    float iw = fmaxf(ix1 - ix0 + 1.f, 0.f), ih = fmaxf(iy1 - iy0 + 1.f, 0.f);      // asymmetric +1, iou_matching.py:36
-    float inter = iw * ih;
-    float v = 1.f - inter / (bw * bh + c[2] * c[3] - inter);
-    if (cand ? tab_tsu[cand[t]] > 1 : (stale && stale[t])) v = INFTY_COST;      // time_since_update > 1, iou_matching.py:86-89
-    if (max_dist > 0.f && v > max_dist) v = flood;
-    cost[idx] = v;
+    const bool is_stale = cand ? tab_tsu[cand[t]] > 1 : (stale && stale[t]);
+    cost[idx] = iou_cost_entry(m, tlwh + (size_t)det_idx[d] * 4, is_stale, max_dist, flood);
 }
 
 // ------------------------------------------------------------------------------- tracker-side NMS
