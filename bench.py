@@ -176,7 +176,7 @@ def committed_traffic(config, kernel, B, mode=""):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 32 frames = 2 s of the pipeline: long enough for external samplers such as rocm-smi to land inside the timed region)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=32, help="frames per step (detector batch).  32 since round 4: the 19x19 / 38x38 layers have 722 / 2888 wave tiles for 1024 SIMDs at 16 frames "
                                                             "(parallelism bound), twice that at 32: conv time per frame -7 %%, end to end +2 %%; 16 = rounds 1-3")
@@ -188,7 +188,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--schedule", default="policy", choices=["policy", "serialized", "two-stream"],
                     help="ReID pass of batch i vs detector pass of batch i+1: serialized on one stream or sharing the CUs from two (yds_pipeline_set_schedule); "
-                         "policy = the library's own choice (serialized for yolov3, two streams for yolov4: pipeline.cpp)")
+                         "policy = the library's own choice (serialized when the frames are resident in HBM: pipeline.cpp)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")

@@ -243,8 +243,8 @@ int yds_pipeline_set_next_injection(yds_pipe *, int set);
  * (no reference counterpart: video_detect.py:134-157 runs them one after the other on one frame; results do not depend on
  * the choice).  min_crops >= 0: from that many crops per batch the ReID pass is enqueued on the detector's stream, between
  * the first layers of the next pass and the rest (every conv kernel has the chip to itself); -1: always two streams sharing
- * the CUs; < -1: the built-in policy (serialize from 256 crops when the detector has few HBM-bound 1x1 layers - yolov3, not
- * yolov4 - and the frames are already in HBM; env YDS_PIPE_SERIAL overrides; measurements in pipeline.cpp).
+ * the CUs; < -1: the built-in policy (serialize from 256 crops per batch when the frames are already in HBM, two streams for
+ * yds_pipeline_step_host and for small batches; env YDS_PIPE_SERIAL overrides; measurements in pipeline.cpp).
  * yds_pipeline_last_schedule: 1 if the last step ran serialized, else 0. */
 int yds_pipeline_set_schedule(yds_pipe *, int min_crops);
 int yds_pipeline_last_schedule(yds_pipe *);

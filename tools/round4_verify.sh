@@ -1,6 +1,9 @@
-# GPU-box verification: the whole -m gpu suite, the default bench line, rocprofv3 summaries + PMC traffic of the same command (both maths)
+# GPU-box verification: the whole -m gpu suite, the bench lines of every configuration, rocprofv3 summaries + PMC traffic of the
+# default command (both maths), the upload-inclusive A/B of the schedules
 python -m pytest tests -m gpu -x -q > gpurun_out/verify_tests.log 2>&1; grep -E "passed|failed" gpurun_out/verify_tests.log | tail -2
-python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 300 gpurun_out/bench_default.json
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 200 gpurun_out/bench_default.json; echo
+for c in cfg3 cfg5; do python bench.py --config $c > gpurun_out/bench_$c.json 2> gpurun_out/bench_$c.err; done
 PMC=1 bash tools/profile_bench.sh cfg2 gpurun_out/prof_cfg2 > gpurun_out/prof_cfg2.log 2>&1
 MATH=f32 PMC=1 bash tools/profile_bench.sh cfg2 gpurun_out/prof_cfg2_f32 > gpurun_out/prof_cfg2_f32.log 2>&1
-ls gpurun_out/prof_cfg2 gpurun_out/prof_cfg2_f32 | head -40
+bash tools/profile_bench.sh cfg3 gpurun_out/prof_cfg3 > gpurun_out/prof_cfg3.log 2>&1
+for s in 0 -1 0 -1; do python tools/upload_prof.py --schedule $s; done 2>&1 | grep frames

@@ -527,17 +527,6 @@ int Darknet::head_layers() const {
     return (int)layers.size();
 }
 
-double Darknet::pointwise_share() const {
-    double total = 0, pw = 0;
-    for (int i = 0; i < (int)layers.size(); ++i) {
-        if (layers[i].type != "convolutional") continue;
-        const double f = conv_flops(conv_args(i, 1));
-        total += f;
-        if (layers[i].ksize == 1) pw += f;
-    }
-    return total > 0 ? pw / total : 0.0;
-}
-
 bool Darknet::forward_resized_part(int batch, int part) {
     if (batch < 1 || batch > batch_max) fail("forward: batch %d outside [1,%d]", batch, batch_max);
     if (math != conv_math()) fail("forward: this network was planned for conv math %d, current mode is %d (re-create it)", math, conv_math());

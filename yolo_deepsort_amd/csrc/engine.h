@@ -68,7 +68,6 @@ public:
     // job between them (pipeline.cpp, serialized schedule); false = this configuration runs in lanes and cannot be split
     bool forward_resized_part(int batch, int part);
     int head_layers() const;
-    double pointwise_share() const;          // share of the network's conv arithmetic in 1x1 layers
     // sliding-window front end (img_detect.py:97-139): windows (x, y, th, tw) of one host frame -> corner-form, window-
     // shifted predictions [n_tiles * total_boxes, attrs] in tiled_pred (windows run in chunks of batch_max)
     void forward_tiles_host(const uint8_t *frame, int h, int w, const int *tiles_xyhw, int n_tiles);

@@ -26,7 +26,6 @@ class Pipeline {
 public:
     Pipeline(Darknet *net, ReidNet *reid, TrackerIface *trk, float conf, float nms_iou, const int32_t *mask, int n_mask)
         : net(net), reid(reid), trk(trk), conf(conf), nms_thres(nms_iou), class_mask(mask, mask + n_mask) {
-        net_pointwise_share = net->pointwise_share();
         for (int k = 0; k < 2; ++k) {
             for (hipEvent_t *e : {&e0[k], &e1[k], &e2[k], &e_nms[k]}) YDS_HIP(hipEventCreate(e));
             nms[k].reset(new NmsWorkspace(4096, net->batch_max));
@@ -236,20 +235,19 @@ public:
         // tail: every conv kernel then has the chip to itself, a launch takes its isolated time, and only the association's
         // small kernels (own high-priority stream) run beside them.  Smaller batches (the frame-by-frame API) keep the two-stream
         // form - a 30-crop ReID pass cannot fill the chip and gains from running beside the detector.
-        // Measured (tools/ab_serial.sh, tools/ab_upload.sh, profiles/r04_serial_schedule_ab.txt; boxes differ by +-1 %), two-stream ->
-        // serialized, 32 frames per step:
-        //   cfg2 yolov3, frames resident in HBM   1505-1525 -> 1518-1527 frames/s (equal), window kernel 423 -> 303 us per launch
-        //                                         in the pipeline (isolated: 316), exact-fp32 mode 561-569 -> 556-560
-        //   cfg2, frames uploaded inside the step 1469-1508 -> 1426-1436 (-4 %: +1.3 ms per step on the detector's stream that
-        //                                         neither the copy's start time nor the result read-back explains - open)
-        //   cfg3 yolov4 1456 -> 1415 (-3 %), cfg5 yolov4 crowd 672 -> 660 (-2 %)
-        // yolov4 spends 19 % of its arithmetic (a third of its time) in HBM-bound 1x1 Mish layers, which do gain from sharing the
-        // chip with the MFMA-bound ReID pass; yolov3 (10 %) does not.  Policy: serialize from 256 crops per batch when the
-        // detector's 1x1 share is below 15 % and the frames are already in HBM (yds_pipeline_step); two streams otherwise.
-        // yds_pipeline_set_schedule / YDS_PIPE_SERIAL=<crops> force a threshold for any network and entry, -1 = never.
+        // Measured on the final tree (tools/ab_serial.sh, tools/ab_upload.sh, profiles/r04_serial_schedule_ab.txt; alternating runs on
+        // one box), two-stream -> serialized, 32 frames per step, frames resident in HBM:
+        //   cfg2 yolov3 1597-1604 -> 1614-1626 frames/s (+1.2 %), window kernel 423 -> 303 us per launch in the pipeline (isolated: 316)
+        //   cfg3 yolov4 1499-1501 -> 1515 (+1.0 %), cfg5 yolov4 crowd 682-693 -> 689-690 (equal), exact-fp32 cfg2 573-575 -> 565-566 (-1.5 %)
+        // (before the association ran as three launches per frame - round 4 - its ~450 small launches per batch gained from the
+        //  two-stream form on yolov4: 1456 -> 1415 then.)  With the frames uploaded inside the step (yds_pipeline_step_host) the
+        // serialized form LOSES 4 % (1469-1508 -> 1426-1436: +1.3 ms per step on the detector's stream that neither the start time of
+        // the copy nor the result read-back explains - open), so that entry keeps two streams.
+        // Policy: serialize from 256 crops per batch when the frames are already in HBM.  yds_pipeline_set_schedule /
+        // YDS_PIPE_SERIAL=<crops> force a threshold for either entry, -1 = never.
         const int serial_min = schedule_min_crops != INT_MIN ? schedule_min_crops
                                : getenv("YDS_PIPE_SERIAL")  ? atoi(getenv("YDS_PIPE_SERIAL"))
-                               : (net_pointwise_share < 0.15 && !uploaded ? 256 : -1);
+                               : (!uploaded ? 256 : -1);
         int next_slot = -1;
         bool next_head_only = false;
         auto launch_next = [&](bool head_only) {                    // detector (+ NMS) of the next batch goes in flight
@@ -350,7 +348,6 @@ public:
     int in_flight_batch = 0;
     hipEvent_t e0[2] = {}, e1[2] = {}, e2[2] = {}, e_nms[2] = {};
     hipEvent_t ev_feat = nullptr;      // this batch's embeddings have been copied for the tracker
-    double net_pointwise_share = 0;
     int schedule_min_crops = INT_MIN;  // yds_pipeline_set_schedule: crops per batch from which the ReID pass is serialized (INT_MIN: policy)
     bool last_serial = false;          // schedule of the last step
     int head_slot = 0;                 // NMS slot of the pass whose head was enqueued last
