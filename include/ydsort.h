@@ -77,6 +77,9 @@ int yds_darknet_batch_max(const yds_net *);
  * single-term fp16 operands (weights and activations rounded to fp16, fp32 accumulation in the matrix cores) instead
  * of the default split-fp16 arithmetic.  Accuracy is fp16-class, not the 1e-3 of the default mode (tests state it). */
 int yds_darknet_set_half(yds_net *, int on);
+/* Storage format of a layer's output as the graph currently runs it: 0 fp32, 1 split-fp16 record (4 bytes per channel), 2 fp16
+ * (2 bytes per channel: half mode only - what model.half() makes of every activation, img_detect.py:49-50).  -1: no such layer. */
+int yds_darknet_layer_format(const yds_net *, int layer);
 int yds_darknet_num_boxes(const yds_net *);
 int yds_darknet_num_attrs(const yds_net *);                 /* 5 + classes                     */
 int yds_darknet_num_layers(const yds_net *);

@@ -397,9 +397,20 @@ def test_half_mode_single_term_fp16():
     net, ref = _nets(cfg, (608, 608), 0, -2.0, batch_max=2)
     x = np.random.RandomState(7).uniform(0, 1, (2, 3, 608, 608)).astype(F32)
     full = np.asarray(net(x))
+    fmt_full = [net.layer_format(i) for i in range(len(net.module_defs))]
+    assert 2 not in fmt_full
     net.half()
     half = np.asarray(net(x))
+    # round 4: half mode moves 2-byte activations (model.half() makes every activation fp16, img_detect.py:49-50): every tensor
+    # from the first downsampling block on is fp16 in HBM (the fused stem / first block keep the 4-byte record, heads stay fp32)
+    fmt_half = [net.layer_format(i) for i in range(len(net.module_defs))]
+    n_conv = sum(1 for i in range(len(net.module_defs)) if fmt_full[i] == 1)
+    assert sum(1 for f in fmt_half if f == 2) >= 0.9 * n_conv, (fmt_half, n_conv)
+    l5 = net.layer_output(5, batch=2)                        # an fp16 tensor read back through the generic accessor
+    assert l5.shape == (2, 128, 152, 152) and np.isfinite(l5).all() and np.abs(l5).max() > 0
+    assert np.array_equal((l5 / 256).astype(np.float16).astype(F32) * 256, l5)     # stored as fp16(x * 2^-8)
     net.float()
+    assert [net.layer_format(i) for i in range(len(net.module_defs))] == fmt_full
     again = np.asarray(net(x))
     assert np.array_equal(full, again)                       # float() restores the default arithmetic exactly
     want = ref(x[:1])

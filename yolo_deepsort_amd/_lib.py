@@ -47,6 +47,7 @@ SIGNATURES = {
     "yds_darknet_set_batch_max": (_I, [_P, _I]),
     "yds_darknet_batch_max": (_I, [_P]),
     "yds_darknet_set_half": (_I, [_P, _I]),
+    "yds_darknet_layer_format": (_I, [_P, _I]),
     "yds_darknet_num_boxes": (_I, [_P]),
     "yds_darknet_num_attrs": (_I, [_P]),
     "yds_darknet_num_layers": (_I, [_P]),

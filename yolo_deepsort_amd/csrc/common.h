@@ -76,7 +76,7 @@ template <typename T> struct DevBuf {
 struct View {
     float *p = nullptr;
     int n = 0, h = 0, w = 0, c = 0, ld = 0;
-    int fmt = 0;             // FMT_F32 or FMT_H16 (h16.h); H16 needs c, ld and the channel offset to be multiples of 32
+    int fmt = 0;             // FMT_F32, FMT_H16 or FMT_F16 (h16.h); H16 needs c, ld and the channel offset to be multiples of 32; F16 (half mode): multiples of 64 channels, ld and offsets in float slots = channels / 2
     size_t pixels() const { return (size_t)n * h * w; }
 };
 
@@ -101,6 +101,7 @@ struct ConvArgs {
 // returns the tile-variant id that was launched (see conv_variant_name)
 int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice
 int conv_default_variant(const ConvArgs &a);
+bool conv_presplit_input(const ConvArgs &a);   // H16, or F16 in half mode: what the LDS-DMA / window kernels fetch as opaque chunks
 // 3x3 RGB stem + MaxPool2d(3, 2, 1) in one kernel (ReID); a.y is the pooled view.  Returns false when the layer does not qualify.
 bool launch_conv_maxpool3s2(const ConvArgs &a, hipStream_t s);
 int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us);   // measured fastest variant

@@ -275,7 +275,7 @@ double conv_flops(const ConvArgs &a) {
     return 2.0 * (double)a.y.pixels() * a.y.c * a.ksize * a.ksize * a.x.c;
 }
 
-double conv_bytes_io(const View &v) { return (double)v.pixels() * v.c * 4.0; }      // fp32 and H16 tensors both hold 4 bytes per channel
+double conv_bytes_io(const View &v) { return (double)v.pixels() * v.c * (v.fmt == FMT_F16 ? 2.0 : 4.0); }      // fp32 and H16 tensors both hold 4 bytes per channel, F16 two
 double conv_bytes(const ConvArgs &a) {
     return conv_bytes_io(a.x) + conv_bytes_io(a.y) + (a.res.p ? conv_bytes_io(a.res) : 0.0) + (double)a.y.c * a.kpad * 4.0;
 }
@@ -306,6 +306,11 @@ ConvKernelArgs make_conv_args(const ConvArgs &a) {
         if (a.y.fmt == FMT_H16 && (a.n_split % 32 || (a.y.c - a.n_split) % 32 || a.y2.ld % 32 || ((uintptr_t)a.y2.p & 127))) fail("conv: merged H16 outputs need 32-channel granularity");
         k.y2 = a.y2.p; k.ldy2 = a.y2.ld; k.n_split = a.n_split;
     }
+    // FMT_F16 (half mode): 64-channel granularity = 32 float slots; read by the 64-channel K steps of the half-mode kernels only
+    if (a.x.fmt == FMT_F16 && (a.terms != 1 || a.x.c % 64 || a.x.ld % 32 || ((uintptr_t)a.x.p & 127))) fail("conv: F16 input needs half mode and 64-channel granularity");
+    if (a.y.fmt == FMT_F16 && (a.y.c % 64 || a.y.ld % 32 || ((uintptr_t)a.y.p & 127))) fail("conv: F16 output needs 64-channel granularity");
+    if (a.y.fmt == FMT_F16 && a.n_split > 0 && (a.n_split % 64 || (a.y.c - a.n_split) % 64 || a.y2.ld % 32 || ((uintptr_t)a.y2.p & 127))) fail("conv: merged F16 outputs need 64-channel granularity");
+    if (a.res.p && (a.res.fmt == FMT_F16) != (a.y.fmt == FMT_F16)) fail("conv: an F16 output takes an F16 residual (and only it does)");
     if (a.x.fmt == FMT_H16 && (a.x.c % 32 || a.x.ld % 32 || ((uintptr_t)a.x.p & 127))) fail("conv: H16 input needs 32-channel granularity");
     if (a.y.fmt == FMT_H16 && (a.y.c % 32 || a.y.ld % 32 || ((uintptr_t)a.y.p & 127))) fail("conv: H16 output needs 32-channel granularity");
     if (a.x.c % 4 || a.x.ld % 4 || ((uintptr_t)a.x.p & 15)) fail("conv: input channels/stride must be multiples of 4 (got c=%d ld=%d)", a.x.c, a.x.ld);
@@ -314,6 +319,11 @@ ConvKernelArgs make_conv_args(const ConvArgs &a) {
     if (a.kpad % KALIGN || a.kpad < k.K) fail("conv: bad kpad %d for K=%d", a.kpad, k.K);
     if ((size_t)a.x.n * a.x.h * a.x.w * a.x.ld >= (1ull << 31)) fail("conv: input tensor too large for 32-bit indexing");
     return k;
+}
+
+// a pre-split activation tensor the LDS-DMA / window kernels can fetch as opaque 16-byte chunks
+bool conv_presplit_input(const ConvArgs &a) {
+    return (a.x.fmt == FMT_H16 && a.x.c % 32 == 0) || (a.x.fmt == FMT_F16 && a.terms == 1 && a.x.c % 64 == 0);
 }
 
 // default tile choice when no measured choice is supplied: widest tile whose grid still fills the chip
@@ -352,6 +362,7 @@ int launch_conv(const ConvArgs &a, hipStream_t s, int variant) {
     if (variant < 0 || variant >= kConvVariants) {
         variant = conv_default_variant(a);
         if (conv_math() == MATH_F16X3) variant = kF32Variants + (variant == 0 ? 0 : variant == 1 ? 2 : 3);
+        if (a.x.fmt == FMT_F16) variant = kF32Variants + 4;          // 2-byte activations: the LDS-DMA kernel reads them, the staged one does not
     }
     if (variant == kDirectVariant) {
         if (!conv_direct_applicable(k)) fail("conv: the direct RGB kernel does not apply to this layer");
@@ -426,7 +437,8 @@ int conv_autotune(const ConvArgs &a, hipStream_t s, float *best_us) {
         if (f16v && f16_variant_is_win(v - kF32Variants) && !conv_win_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
         if (f16v && v - kF32Variants == 10 && (a.terms == 1 || !conv_win16_small_applicable(make_conv_args(a)))) return conv_autotune_measured(a, s, best_us);
         if (f16v && f16_variant_is_win2(v - kF32Variants) && !conv_win2_applicable(make_conv_args(a))) return conv_autotune_measured(a, s, best_us);
-        if (!(presplit && (a.x.fmt != FMT_H16 || a.x.c % 32))) return v;
+        if (a.x.fmt == FMT_F16 && !(f16v && (f16_variant_is_dma(v - kF32Variants) || f16_variant_is_win(v - kF32Variants)))) return conv_autotune_measured(a, s, best_us);
+        if (!(presplit && !conv_presplit_input(a))) return v;
     }
     if (conv_math() == MATH_F16X3 && a.w16 && a.terms != 1 && a.n_split == 0 && conv_splitk_preferred(make_conv_args(a))) return kF32Variants + 14;   // by rule (see there)
     const std::string key = tune_key(a);
@@ -456,8 +468,9 @@ static int conv_autotune_measured(const ConvArgs &a, hipStream_t s, float *best_
         if (v == 3 && a.y.c > 64) continue;             // 128x32 only makes sense for narrow layers
         const int fv = v - kF32Variants;                // f16x3 variant index (meaningful for kF32Variants <= v < kDirectVariant)
         const bool f16v = v >= kF32Variants && v != kDirectVariant;
-        if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv) || f16_variant_is_win2(fv) || f16_variant_is_splitk(fv)) && (a.x.fmt != FMT_H16 || a.x.c % 32)) continue;   // need a pre-split input
+        if (f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv) || f16_variant_is_win2(fv) || f16_variant_is_splitk(fv)) && !conv_presplit_input(a)) continue;   // need a pre-split input
         if (f16v && f16_variant_is_splitk(fv)) continue;                                  // selected by rule in conv_autotune, never by timing
+        if (a.x.fmt == FMT_F16 && !(f16v && (f16_variant_is_dma(fv) || f16_variant_is_win(fv)))) continue;   // 2-byte activations: LDS-DMA and window kernels only
         if (f16v && f16_variant_is_win2(fv) && (!conv_win2_applicable(make_conv_args(a)) || a.y.c < 128)) continue;
         if (f16v && f16_variant_is_win(fv) && !conv_win_applicable(make_conv_args(a))) continue;
         if (f16v && f16_variant_is_win(fv) && fv > 8 && a.y.c > 64) continue;          // 64-wide window tiles are for 64-filter layers

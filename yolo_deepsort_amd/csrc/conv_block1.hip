@@ -64,6 +64,9 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
     const int brow = wn * 32 + (lane & 31);
 
     // the next tile's input pixels are fetched into registers while this tile is computed
+    // (half mode with 2-byte activations: the block input is an FMT_F16 tensor - a pixel's 64 channels are 128 contiguous bytes; its
+    //  eight 16-byte pieces become the hi chunks 0-3 of the two LDS rows, the lo chunks are zero, phase A runs unchanged)
+    const bool xs = p2.fmt_x == FMT_F16;
     f32x4 nxt[XLOADS];
     auto fetch = [&](int tl) {
         const int img = tl / (tiles_y * tiles_x), rem = tl - img * (tiles_y * tiles_x);
@@ -73,8 +76,9 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
             const int i = tid + l * NT, c = i & 7, row = i >> 3, g = row / PPIX, pr = row - g * PPIX;
             const int iy = iy0 + pr / PC, ix = ix0 + pr % PC;
             nxt[l] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < XCHUNKS && tl < n_tiles && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                nxt[l] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p2.x + ((size_t)(img * H + iy) * W + ix) * p2.ldx) + g * 128 + c * 16);
+            if (i < XCHUNKS && tl < n_tiles && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && !(xs && c >= 4))
+                nxt[l] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p2.x + ((size_t)(img * H + iy) * W + ix) * p2.ldx) +
+                                                          (xs ? (g * 4 + c) * 16 : g * 128 + c * 16));
         }
     };
     fetch(blockIdx.x);
@@ -171,9 +175,9 @@ template <int ACT> void launch_inst(const ConvKernelArgs &k2, const ConvKernelAr
 }  // namespace
 
 bool conv_block1_applicable(const ConvKernelArgs &k2, const ConvKernelArgs &k3) {
-    return k2.Cin == CIN && k2.ksize == 1 && k2.stride == 1 && k2.Cout == CMID && k2.res_mode == RES_NONE && k2.fmt_x == FMT_H16 &&
+    return k2.Cin == CIN && k2.ksize == 1 && k2.stride == 1 && k2.Cout == CMID && k2.res_mode == RES_NONE && (k2.fmt_x == FMT_H16 || k2.fmt_x == FMT_F16) &&
            k3.Cin == CMID && k3.ksize == 3 && k3.stride == 1 && k3.pad == 1 && k3.Cout == BN && k3.res_mode == RES_AFTER_ACT &&
-           k3.fmt_r == FMT_H16 && k3.fmt_y == FMT_H16 && k3.res == k2.x && k3.ldr == k2.ldx && k3.H == k2.H && k3.W == k2.W &&
+           k3.fmt_r == k2.fmt_x && k3.fmt_y == k2.fmt_x && k3.res == k2.x && k3.ldr == k2.ldx && k3.H == k2.H && k3.W == k2.W &&
            k2.act == k3.act && (k2.act == ACT_LEAKY || k2.act == ACT_MISH);
 }
 

@@ -124,8 +124,9 @@ __device__ __forceinline__ void conv_epilogue_core(const ConvKernelArgs &p, Stor
     // through ONE uniform branch, so its loops carry no format tests (the generic form spent a third of its instructions on
     // exec-mask bookkeeping and re-tested the formats in every iteration).
     constexpr int PER_PASS = ROWS / RSTEP, NRES = RES != RES_NONE ? WM * PER_PASS : 1;
-    auto sweep = [&](auto yh_c, auto rh_c) {
-        constexpr bool YH = decltype(yh_c)::value, RH = decltype(rh_c)::value;
+    auto sweep = [&](auto yf_c, auto rf_c) {
+        constexpr int YF = decltype(yf_c)::value, RF = decltype(rf_c)::value;          // TensorFmt of the output / the residual
+        constexpr bool YH = YF == FMT_H16, RH = RF == FMT_H16, YS = YF == FMT_F16, RS = RF == FMT_F16;
         // The residual rows of ALL passes are fetched up front: the loads are in flight while the tile goes through LDS,
         // instead of paying one exposed global-load latency per pass.
         float4 rraw[NRES];
@@ -140,6 +141,9 @@ __device__ __forceinline__ void conv_epilogue_core(const ConvKernelArgs &p, Stor
                         const char *g = reinterpret_cast<const char *>(rp + (n & ~31)) + (n & 31) * 2;
                         const float2 hi = *reinterpret_cast<const float2 *>(g), lo = *reinterpret_cast<const float2 *>(g + 64);
                         rraw[q] = make_float4(hi.x, hi.y, lo.x, lo.y);
+                    } else if (RS) {                                               // FMT_F16: four channels = 8 bytes, ldr in float slots
+                        const float2 h = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(rp) + n * 2);
+                        rraw[q] = make_float4(h.x, h.y, 0.f, 0.f);
                     } else if (n_vec) {
                         rraw[q] = *reinterpret_cast<const float4 *>(rp + n);
                     } else {
@@ -168,6 +172,11 @@ __device__ __forceinline__ void conv_epilogue_core(const ConvKernelArgs &p, Stor
                         uh.f = make_float2(t.x, t.y);
                         ul.f = make_float2(t.z, t.w);
                         h16_decode4(uh.h, ul.h, rs);
+                    } else if (RS) {
+                        union { float2 f; h16x4 h; } uh;
+                        uh.f = make_float2(t.x, t.y);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) rs[k] = (float)uh.h[k] * (1.f / H16_A_SCALE);
                     } else { rs[0] = t.x; rs[1] = t.y; rs[2] = t.z; rs[3] = t.w; }
                 }
                 float o[4] = {v.x + bias4.x, v.y + bias4.y, v.z + bias4.z, v.w + bias4.w};
@@ -195,6 +204,17 @@ __device__ __forceinline__ void conv_epilogue_core(const ConvKernelArgs &p, Stor
                     const int nq = ny & ~7;                                         // first channel of the lane pair
                     char *g = reinterpret_cast<char *>(yp + (nq & ~31)) + (nq & 31) * 2 + (odd ? 64 : 0);
                     if (live) *reinterpret_cast<float4 *>(g) = out.f;
+                } else if (YS) {
+                    // FMT_F16: the even lane of a pair stores both lanes' channel quads, 8 consecutive fp16 = one 16-byte store
+                    union { h16x4 h; int i[2]; } mine, other;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mine.h[k] = (_Float16)(o[k] * H16_A_SCALE);
+                    other.i[0] = __builtin_amdgcn_update_dpp(mine.i[0], mine.i[0], 0xB1, 0xF, 0xF, false);
+                    other.i[1] = __builtin_amdgcn_update_dpp(mine.i[1], mine.i[1], 0xB1, 0xF, 0xF, false);
+                    union { h16x4 h[2]; float4 f; } out;
+                    out.h[0] = mine.h;
+                    out.h[1] = other.h;
+                    if (live && !(c4 & 1)) *reinterpret_cast<float4 *>(reinterpret_cast<char *>(yp) + ny * 2) = out.f;
                 } else if (live) {
                     if (n_vec) *reinterpret_cast<float4 *>(yp + ny) = make_float4(o[0], o[1], o[2], o[3]);
                     else { yp[ny] = o[0]; if (n + 1 < p.Cout) yp[ny + 1] = o[1]; if (n + 2 < p.Cout) yp[ny + 2] = o[2]; }
@@ -203,13 +223,20 @@ __device__ __forceinline__ void conv_epilogue_core(const ConvKernelArgs &p, Stor
             if (!ONE_PASS && pass + 1 < WM) __syncthreads();
         }
     };
+    // (FMT_F16 outputs exist in half mode only and take an FMT_F16 residual or none: the planner keeps both sides of a shortcut in
+    //  one format, make_conv_args refuses anything else)
+    using F32c = std::integral_constant<int, FMT_F32>;
+    using H16c = std::integral_constant<int, FMT_H16>;
+    using F16c = std::integral_constant<int, FMT_F16>;
     const bool yh = p.fmt_y == FMT_H16, rh = RES != RES_NONE && p.fmt_r == FMT_H16;
-    if (yh) {
-        if (rh) sweep(std::true_type{}, std::true_type{});
-        else sweep(std::true_type{}, std::false_type{});
+    if (p.fmt_y == FMT_F16) {
+        sweep(F16c{}, F16c{});
+    } else if (yh) {
+        if (rh) sweep(H16c{}, H16c{});
+        else sweep(H16c{}, F32c{});
     } else {
-        if (rh) sweep(std::false_type{}, std::true_type{});
-        else sweep(std::false_type{}, std::false_type{});
+        if (rh) sweep(F32c{}, H16c{});
+        else sweep(F32c{}, F32c{});
     }
 }
 constexpr size_t conv_stage_bytes(int BM, int BN) { return (size_t)BM * (BN + 4) * sizeof(float); }

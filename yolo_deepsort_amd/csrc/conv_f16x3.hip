@@ -280,16 +280,20 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     // every instruction (row bases are multiples of 8) and bit 3 of r is bit 0 of (q*NW + wave)
     // TERMS = 4 (half mode, 64 channels per K step): an LDS row is gathered from the hi halves of two consecutive channel groups -
     // logical chunks 0-3 = chunks 0-3 of group 2q's record, 4-7 = chunks 0-3 of group 2q+1's (see conv_win.hip)
+    // An FMT_F16 activation tensor (2-byte half-mode activations, TERMS = 4 only) already IS that gathered row: 64 channels = 128
+    // contiguous bytes, chunk c in place; its strides are in float slots, so only the byte step per channel differs (xbpc).
     constexpr int KC = TERMS == 4 ? 64 : 32;                    // channels per K step
-    auto src_chunk = [&](int q) {
+    const bool xs = TERMS == 4 && p.fmt_x == FMT_F16;
+    const int xbpc = xs ? 2 : 4;                                // bytes per channel of the activation tensor
+    auto src_chunk = [&](int q, bool act) {                     // act: activation row (filter rows always come from the split record)
         const int c = dpos ^ ((((q * NW + wave) * 8 + drow) >> 1) & 7);
-        return (TERMS == 4 ? ((c >> 2) << 3) + (c & 3) : c) * 16;
+        return ((TERMS == 4 && !(act && xs)) ? ((c >> 2) << 3) + (c & 3) : c) * 16;
     };
     const char *w_src[B_INST];
 #pragma unroll
     for (int q = 0; q < B_INST; ++q) {
         const int row = (q * NW + wave) * 8 + drow;
-        w_src[q] = reinterpret_cast<const char *>(p.w) + (size_t)min(n0 + row, p.Cout - 1) * p.Kpad * 4 + src_chunk(q);
+        w_src[q] = reinterpret_cast<const char *>(p.w) + (size_t)min(n0 + row, p.Cout - 1) * p.Kpad * 4 + src_chunk(q, false);
     }
     // split-K (gridDim.y > 1): this workgroup accumulates K tiles [t_begin, t_begin + nk) only and writes raw fp32 partial
     // sums into slab blockIdx.y of the workspace p.y (the launcher passes zero bias / linear / no residual / fp32 output);
@@ -311,7 +315,7 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
         for (int q = 0; q < A_INST; ++q) {
             int iy = a_iy[q] + kh, ix = a_ix[q] + kw;
             bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            a_src[q] = ok ? reinterpret_cast<const char *>(p.x + (a_base[q] + (kh * p.W + kw) * p.ldx)) + src_chunk(q) : zero_page;
+            a_src[q] = ok ? reinterpret_cast<const char *>(p.x + (a_base[q] + (kh * p.W + kw) * p.ldx)) + src_chunk(q, true) : zero_page;
         }
     };
     set_tap();
@@ -319,7 +323,7 @@ void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
     auto piece = [&](int stage, int q) {
         char *sa = ring + stage * STAGE, *sb = sa + A_BYTES;
         if (q < A_INST) {
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[q] + kc * 4), (lds_void_t *)(sa + (q * NW + wave) * 8 * ROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(a_src[q] + kc * xbpc), (lds_void_t *)(sa + (q * NW + wave) * 8 * ROW), 16, 0, 0);
         } else {
             const int b = q - A_INST;
             __builtin_amdgcn_global_load_lds((glb_void_t *)w_src[b], (lds_void_t *)(sb + (b * NW + wave) * 8 * ROW), 16, 0, 0);
@@ -468,9 +472,10 @@ template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS> s
 }
 
 template <int BM, int BN, int WM, int WN, int NS> static void launch_cfg_dma(const ConvKernelArgs &k, hipStream_t s) {
-    if (k.fmt_x != FMT_H16 || k.Cin % 32) fail("conv: the LDS-DMA kernel needs a pre-split (H16) input");
+    const bool xs = k.fmt_x == FMT_F16;                          // 2-byte activations (half mode): the 64-channel K steps read them in place
+    if (xs ? (k.terms != 1 || k.Cin % 64) : (k.fmt_x != FMT_H16 || k.Cin % 32)) fail("conv: the LDS-DMA kernel needs a pre-split (H16, or F16 in half mode) input");
     if ((size_t)k.Cin * 4 + 128 > (size_t)ZERO_PAGE_BYTES) fail("conv: %d input channels exceed the zero page of the LDS-DMA kernel", k.Cin);
-    if (k.terms == 1 && k.Cin % 64 == 0 && !getenv("YDS_HALF_NARROW")) {      // half mode, 64 channels per K step
+    if (k.terms == 1 && k.Cin % 64 == 0 && (xs || !getenv("YDS_HALF_NARROW"))) {      // half mode, 64 channels per K step
 #define YDS_CALL(A, R) launch_inst_dma<BM, BN, WM, WN, NS, A, R, 4>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)
 #undef YDS_CALL
@@ -593,6 +598,7 @@ template <int BM, int BN, int ACT, int RES, int AIN> static void launch_inst16(C
 }
 
 template <int BM, int BN> static void launch_cfg16(const ConvKernelArgs &k, hipStream_t s) {
+    if (k.fmt_x == FMT_F16) fail("conv: the register-staged kernel does not read 2-byte (F16) activations");
     if (k.fmt_x == FMT_H16) {
 #define YDS_CALL(A, R) launch_inst16<BM, BN, A, R, FMT_H16>(k, s)
         YDS_DISPATCH_ACT_RES(k, YDS_CALL)

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
     constexpr int GROUP_BYTES = TERMS == 4 ? 256 : 128;
     // logical 16-byte chunk c of an LDS row -> chunk of the global record(s): TERMS = 4 takes chunks 0-3 (the hi halves) of two records
     auto gchunk = [&](int c) { return TERMS == 4 ? ((c >> 2) << 3) + (c & 3) : c; };
+    // An FMT_F16 activation tensor (2-byte half-mode activations, TERMS = 4 only) already is the gathered row: 64 channels = 128
+    // contiguous bytes with chunk c in place; the filters keep the split record.  Strides stay in float slots (h16.h).
+    const bool xs = TERMS == 4 && p.fmt_x == FMT_F16;
+    const int x_group_bytes = xs ? 128 : GROUP_BYTES;
     const int drow = lane >> 3, dpos = lane & 7;
     // window pieces: piece pc covers window rows pc*8 .. pc*8+7, wave w issues pieces w, w+8, ...; row j <-> flat input
     // pixel m0 - W - 1 + j (clamped into the tensor: rows outside it are never read unmasked); offsets in 16-byte units
@@ -87,8 +91,9 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         const int pc = min(k * NW + wave, npieces - 1);        // surplus instructions repeat the last piece (same data, same place)
         const int j = pc * 8 + drow;
         const int f = min(max(m0 - W - 1 + j, 0), p.M - 1);
-        const unsigned off16 = (unsigned)f * (unsigned)(p.ldx / 4) + (unsigned)gchunk(dpos ^ ((j >> 1) & 7));
-        const char *src = x_bytes + (size_t)g * GROUP_BYTES + ((size_t)off16 << 4);
+        const int c = dpos ^ ((j >> 1) & 7);
+        const unsigned off16 = (unsigned)f * (unsigned)(p.ldx / 4) + (unsigned)(xs ? c : gchunk(c));
+        const char *src = x_bytes + (size_t)g * x_group_bytes + ((size_t)off16 << 4);
         __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(smem + (g & 1) * WB + pc * 8 * ROW), 16, 0, 0);
     };
     auto b_piece = [&](int g, int tap, int stage, int b) {       // filter rows of K chunk (tap, g)
@@ -295,7 +300,8 @@ void conv_win_clock(unsigned long long *cycles_ticks, bool reset) {
 }
 
 bool conv_win_applicable(const ConvKernelArgs &k) {
-    if (!(k.ksize == 3 && k.stride == 1 && k.pad == 1 && k.fmt_x == FMT_H16 && k.Cin % 32 == 0 && k.H == k.Ho && k.W == k.Wo)) return false;
+    const bool presplit = (k.fmt_x == FMT_H16 && k.Cin % 32 == 0) || (k.fmt_x == FMT_F16 && k.terms == 1 && k.Cin % 64 == 0);
+    if (!(k.ksize == 3 && k.stride == 1 && k.pad == 1 && presplit && k.H == k.Ho && k.W == k.Wo)) return false;
     const int wrows = window_rows(k.W), nbuf = k.Cin == 32 ? 1 : 2;
     // several channel groups: the next group's window is fetched by at most APW instructions per wave while this one is
     // consumed (two buffers); a single group needs one buffer only, which admits much wider images
@@ -306,7 +312,7 @@ bool conv_win_applicable(const ConvKernelArgs &k) {
 
 void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s) {
     if (!conv_win_applicable(k)) fail("conv: the window-resident kernel needs a 3x3 stride-1 layer with a pre-split input and W <= 95 (W <= 318 for 32 input channels)");
-    if (k.terms == 1 && k.Cin % 64 == 0 && !getenv("YDS_HALF_NARROW")) {   // half mode, 64 channels per step (YDS_HALF_NARROW: tuning aid, the 32-channel form)
+    if (k.terms == 1 && k.Cin % 64 == 0 && (k.fmt_x == FMT_F16 || !getenv("YDS_HALF_NARROW"))) {   // half mode, 64 channels per step (YDS_HALF_NARROW: tuning aid, the 32-channel form)
         if (shape == 0) {
 #define YDS_CALL(A, R) launch_inst_win<128, 4, 2, A, R, 4>(k, s)
             YDS_DISPATCH_ACT_RES(k, YDS_CALL)

@@ -239,14 +239,6 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
     //      lives in it sits at 32-channel granularity; the image and the 255-channel heads stay fp32.
     math = conv_math();
     std::vector<char> h16_ok(L, math == MATH_F16X3 ? 1 : 0);
-    auto owner_of = [&](int j, int &off) {
-        const Layer &l = layers[j];
-        if (l.type == "route" && l.refs.size() > 1) { off = 0; return j; }
-        int r = l.root;
-        if (storage[r].redirected) { off = storage[r].coff + l.coff; return storage[r].into; }
-        off = l.coff;
-        return r;
-    };
     for (int j = 0; j < L; ++j) {
         if (layers[j].type == "yolo") continue;
         int off = 0, o = owner_of(j, off);
@@ -286,7 +278,69 @@ Darknet::Darknet(const std::string &cfg_text, int img_h, int img_w, int batch_ma
         a.merge_next = i + 2;
         b.merged_into = i;
     }
+    plan_half_formats();
     allocate_buffers();
+}
+
+int Darknet::owner_of(int j, int &off) const {
+    const Layer &l = layers[j];
+    if (l.type == "route" && l.refs.size() > 1) { off = 0; return j; }
+    int r = l.root;
+    if (storage[r].redirected) { off = storage[r].coff + l.coff; return storage[r].into; }
+    off = l.coff;
+    return r;
+}
+
+// Half mode with 2-byte activations (round 4; reference: model.half() converts every activation to fp16, img_detect.py:49-50).
+// The half-mode kernels read the hi halves only, so a buffer can hold just those (FMT_F16, h16.h: half the HBM bytes of the H16
+// record) when everything that lives in it sits at 64-channel granularity (the 64-channel K steps of the LDS-DMA and window kernels
+// fetch 128 contiguous bytes per pixel) and every kernel that touches it takes the format:
+//   * any convolution writes it (shared epilogue), the LDS-DMA and window kernels read it; maxpool / shortcut-add go through the
+//     generic accessors, upsample and route copies are byte-wise;
+//   * the fused stem writes it through the same epilogue; the fused first residual block reads an F16 input patch into the hi
+//     chunks of its LDS rows (lo = 0) and takes input, residual and output in ONE format (tied below);
+//   * a convolution and its fused shortcut source share one format, so do the two outputs of a merged CSP launch and both sides
+//     of a route copy - disagreeing pairs fall back to H16 together.
+// Buffers keep their (H16-sized) allocation; an F16 view addresses it in float slots (ld / 2, channel offset / 2).
+void Darknet::plan_half_formats() {
+    const int L = (int)layers.size();
+    for (Storage &st : storage) st.fmt_half = st.fmt;
+    const bool off = getenv("YDS_HALF_H16") != nullptr;          // tuning aid, read at plan time: round 3's half mode (H16 tensors, hi halves read)
+    if (!half_mode || off || math != MATH_F16X3) return;
+    std::vector<char> ok(L, 0);
+    for (int i = 0; i < L; ++i) ok[i] = storage[i].owns && storage[i].fmt == FMT_H16 && storage[i].ld % 64 == 0;
+    auto own = [&](int j) { int off = 0; return owner_of(j, off); };
+    for (int j = 0; j < L; ++j) {
+        if (layers[j].type == "yolo") continue;
+        int off = 0, o = owner_of(j, off);
+        if (o >= 0 && (off % 64 || layers[j].c % 64)) ok[o] = 0;
+    }
+    if (block1_at >= 0) ok[own(block1_at)] = 0;                  // (32 channels: never written by the fused block anyway)
+    for (int pass = 0; pass < L; ++pass) {
+        bool changed = false;
+        auto tie = [&](int a, int b) {
+            if (a >= 0 && b >= 0 && ok[a] != ok[b]) { ok[a] = ok[b] = 0; changed = true; }
+        };
+        for (int i = 0; i < L; ++i) {
+            const Layer &l = layers[i];
+            for (auto &cp : l.copies) tie(own(cp.first), i);
+            if (l.type == "convolutional" && l.fused_res >= 0) tie(own(i), own(l.fused_res));
+            if (l.type == "convolutional" && l.merge_next >= 0) tie(own(i), own(l.merge_next));
+            if (l.type == "upsample") tie(own(i), own(l.src));
+            if (i == block1_at && l.src >= 0) tie(own(l.src), own(i + 1));
+        }
+        if (!changed) break;
+    }
+    for (int i = 0; i < L; ++i)
+        if (ok[i]) storage[i].fmt_half = FMT_F16;
+}
+
+void Darknet::set_half(bool on) {
+    if (on == half_mode) return;
+    YDS_HIP(hipStreamSynchronize(stream));
+    half_mode = on;
+    plan_half_formats();
+    stem_checked_reset();
 }
 
 // Everything whose size depends on batch_max.  set_batch_max() re-runs it inside the SAME object, so handles held by
@@ -335,21 +389,23 @@ View Darknet::view(int i, int batch) const {
     int r = l.root;
     View v;
     v.n = batch; v.h = l.h; v.w = l.w; v.c = l.c;
+    // (strides and channel offsets of an F16 buffer count float slots: half the channels, h16.h)
     if (l.type == "route" && l.refs.size() > 1) {
-        v.p = storage[i].buf.p; v.ld = storage[i].ld; v.fmt = storage[i].fmt;
+        v.fmt = half_mode ? storage[i].fmt_half : storage[i].fmt;
+        v.p = storage[i].buf.p; v.ld = fmt_slots(v.fmt, storage[i].ld);
         v.p += (size_t)lane_img0 * l.h * l.w * v.ld;
         return v;
     }
     const Storage &st = storage[r];
     if (st.redirected) {
         const Storage &dst = storage[st.into];
-        v.p = dst.buf.p + st.coff + l.coff;
-        v.ld = dst.ld;
-        v.fmt = dst.fmt;
+        v.fmt = half_mode ? dst.fmt_half : dst.fmt;
+        v.p = dst.buf.p + fmt_slots(v.fmt, st.coff + l.coff);
+        v.ld = fmt_slots(v.fmt, dst.ld);
     } else {
-        v.p = st.buf.p + l.coff;
-        v.ld = st.ld;
-        v.fmt = st.fmt;
+        v.fmt = half_mode ? st.fmt_half : st.fmt;
+        v.p = st.buf.p + fmt_slots(v.fmt, l.coff);
+        v.ld = fmt_slots(v.fmt, st.ld);
     }
     v.p += (size_t)lane_img0 * l.h * l.w * v.ld;                // image range of the lane being enqueued (run_graph)
     return v;
@@ -608,7 +664,7 @@ void Darknet::run_lane(int first, int batch, hipStream_t stream, int l0, int l1)
                 View dst = view(i, batch);
                 for (auto &cp : l.copies) {
                     View d = dst;
-                    d.p += cp.second;
+                    d.p += fmt_slots(dst.fmt, cp.second);
                     launch_copy(view(cp.first, batch), d, stream);
                 }
             }
@@ -694,7 +750,7 @@ bool Darknet::stem_fused(int batch) {
     if (off || !stem_fusable || conv_math() != MATH_F16X3 || !layers[0].loaded || !layers[1].loaded) return false;
     if (stem_checked != batch) {
         ConvArgs a0 = conv_args(0, batch), a1 = conv_args(1, batch);
-        stem_ok = a1.w16 && a1.y.fmt == FMT_H16 && conv_stem2_applicable(make_conv_args(a0), make_conv_args(a1));
+        stem_ok = a1.w16 && a1.y.fmt != FMT_F32 && conv_stem2_applicable(make_conv_args(a0), make_conv_args(a1));
         stem_checked = batch;
     }
     return stem_ok;
@@ -841,9 +897,12 @@ int yds_darknet_batch_max(const yds_net *n) { return n->d->batch_max; }
 int yds_darknet_set_half(yds_net *n, int on) {
     YDS_API_BEGIN
     if (on && n->d->math != yds::MATH_F16X3) yds::fail("half mode needs the split-fp16 tensor formats (conv math f16x3)");
-    n->d->half_mode = on != 0;
-    n->d->stem_checked_reset();
+    n->d->set_half(on != 0);
     YDS_API_END
+}
+int yds_darknet_layer_format(const yds_net *n, int layer) {
+    if (!n || layer < 0 || layer >= (int)n->d->layers.size() || n->d->layers[layer].type == "yolo") return -1;
+    return n->d->view(layer, 1).fmt;
 }
 int yds_darknet_num_boxes(const yds_net *n) { return n->d->total_boxes; }
 int yds_darknet_num_attrs(const yds_net *n) { return n->d->attrs; }

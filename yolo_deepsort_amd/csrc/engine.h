@@ -49,6 +49,7 @@ struct Storage {
     DevBuf<float> buf;
     int ld = 0;
     int fmt = 0;                          // TensorFmt of the owned buffer (H16 only in f16x3 mode, 32-channel granularity)
+    int fmt_half = 0;                     // ... while the network is in half mode: FMT_F16 where every user of the buffer can take it (plan_half_formats)
     bool owns = false;                    // this layer owns `buf` (sized by batch_max)
     bool redirected = false;              // producer writes into a slice of storage[into]
     int into = -1, coff = 0;
@@ -89,6 +90,9 @@ public:
     int math = 0;                            // conv arithmetic the plan (tensor formats) was built for
     bool half_mode = false;                  // Darknet.half(): single-term fp16 operands in the LDS-DMA / window kernels
     void stem_checked_reset() { stem_checked = block1_checked = -1; }
+    void set_half(bool on);                  // half mode on / off: re-plans the activation formats (2-byte tensors while it is on)
+    void plan_half_formats();
+    int owner_of(int layer, int &off) const; // layer -> the storage its view lives in and the channel offset of that view
     int total_boxes = 0, attrs = 0;
     std::vector<Layer> layers;
     std::vector<Storage> storage;

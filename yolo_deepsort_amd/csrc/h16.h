@@ -12,7 +12,13 @@
 
 namespace yds {
 
-enum TensorFmt { FMT_F32 = 0, FMT_H16 = 1 };
+// FMT_F16 (round 4, half mode only): the hi halves alone, 2 bytes per channel - per pixel and group of 64 channels 128 bytes =
+// [64 x fp16(x * 2^-8)], i.e. a plain NHWC fp16 tensor of scaled values.  Views of such a tensor keep their strides and channel
+// offsets in FLOAT SLOTS (4-byte units) like every other view: `ld` = channels / 2 and a channel offset c sits c / 2 slots in, so
+// byte-wise copies, nearest upsampling and 64-channel-granular concatenation stay format agnostic (`fmt_slots`).
+enum TensorFmt { FMT_F32 = 0, FMT_H16 = 1, FMT_F16 = 2 };
+// float slots that `c` channels occupy in a pixel of format `fmt`
+__host__ __device__ inline int fmt_slots(int fmt, int c) { return fmt == FMT_F16 ? c / 2 : c; }
 
 constexpr float H16_A_SCALE = 1.f / 256.f, H16_LO_SCALE = 2048.f;
 
@@ -47,9 +53,23 @@ __device__ __forceinline__ void h16_store4(float *pixel, int c, const float v[4]
     *reinterpret_cast<h16x4 *>(g + 64) = lo;
 }
 
+// FMT_F16: four consecutive channels = 8 bytes at byte offset 2 c of the pixel
+__device__ __forceinline__ void f16_load4(const float *pixel, int c, float v[4]) {
+    const h16x4 h = *reinterpret_cast<const h16x4 *>(reinterpret_cast<const char *>(pixel) + c * 2);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (float)h[k] * (1.f / H16_A_SCALE);
+}
+__device__ __forceinline__ void f16_store4(float *pixel, int c, const float v[4]) {
+    h16x4 h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) h[k] = (_Float16)(v[k] * H16_A_SCALE);
+    *reinterpret_cast<h16x4 *>(reinterpret_cast<char *>(pixel) + c * 2) = h;
+}
+
 // generic 4-channel accessors on a (pointer, fmt) pair
 __device__ __forceinline__ void load4(const float *pixel, int c, int fmt, float v[4]) {
     if (fmt == FMT_H16) h16_load4(pixel, c, v);
+    else if (fmt == FMT_F16) f16_load4(pixel, c, v);
     else {
         float4 t = *reinterpret_cast<const float4 *>(pixel + c);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -57,6 +77,7 @@ __device__ __forceinline__ void load4(const float *pixel, int c, int fmt, float 
 }
 __device__ __forceinline__ void store4(float *pixel, int c, int fmt, const float v[4]) {
     if (fmt == FMT_H16) h16_store4(pixel, c, v);
+    else if (fmt == FMT_F16) f16_store4(pixel, c, v);
     else *reinterpret_cast<float4 *>(pixel + c) = make_float4(v[0], v[1], v[2], v[3]);
 }
 

@@ -82,8 +82,10 @@ __global__ void upsample_kernel(const float *x, float *y, int N, int H, int W, i
 void launch_upsample(const View &x, const View &y, int stride, hipStream_t s) {
     if (x.c % 4 || x.ld % 4 || y.ld % 4) fail("upsample: channels must be a multiple of 4");
     if (x.fmt != y.fmt) fail("upsample: source and destination formats differ");
-    size_t total = y.pixels() * (x.c / 4);
-    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x.p, y.p, x.n, x.h, x.w, x.c, x.ld, y.ld, stride);
+    const int slots = fmt_slots(x.fmt, x.c);                    // byte-wise copy: an F16 pixel holds c / 2 float slots
+    if (slots % 4) fail("upsample: channels must fill whole 16-byte pieces");
+    size_t total = y.pixels() * (slots / 4);
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, s, x.p, y.p, x.n, x.h, x.w, slots, x.ld, y.ld, stride);
     YDS_HIP(hipGetLastError());
 }
 
@@ -108,11 +110,12 @@ __global__ void copy_scalar_kernel(const float *x, float *y, size_t pixels, int 
 
 void launch_copy(const View &x, const View &y, hipStream_t s) {
     if (x.fmt != y.fmt) fail("copy: source and destination formats differ");
-    bool vec = !(x.c % 4 || x.ld % 4 || y.ld % 4 || ((uintptr_t)x.p & 15) || ((uintptr_t)y.p & 15));
+    const int slots = fmt_slots(x.fmt, x.c);                    // byte-wise copy: an F16 pixel holds c / 2 float slots
+    bool vec = !(slots % 4 || x.ld % 4 || y.ld % 4 || ((uintptr_t)x.p & 15) || ((uintptr_t)y.p & 15));
     if (vec)
-        hipLaunchKernelGGL(copy_kernel, dim3(grid_for(x.pixels() * (x.c / 4))), dim3(256), 0, s, x.p, y.p, x.pixels(), x.c, x.ld, y.ld);
+        hipLaunchKernelGGL(copy_kernel, dim3(grid_for(x.pixels() * (slots / 4))), dim3(256), 0, s, x.p, y.p, x.pixels(), slots, x.ld, y.ld);
     else
-        hipLaunchKernelGGL(copy_scalar_kernel, dim3(grid_for(x.pixels() * x.c)), dim3(256), 0, s, x.p, y.p, x.pixels(), x.c, x.ld, y.ld);
+        hipLaunchKernelGGL(copy_scalar_kernel, dim3(grid_for(x.pixels() * slots)), dim3(256), 0, s, x.p, y.p, x.pixels(), slots, x.ld, y.ld);
     YDS_HIP(hipGetLastError());
 }
 
@@ -165,9 +168,9 @@ __global__ void nhwc_to_nchw_kernel(const float *x, float *dst, int N, int C, in
         int c = t % C;
         int n = t / C;
         const float *pixel = x + ((size_t)(n * H + yh) * W + xw) * ldx;
-        if (fmt == FMT_H16) {
+        if (fmt == FMT_H16 || fmt == FMT_F16) {
             float v[4];
-            h16_load4(pixel, c & ~3, v);
+            load4(pixel, c & ~3, fmt, v);
             dst[idx] = v[c & 3];
         } else {
             dst[idx] = pixel[c];

@@ -188,6 +188,10 @@ class Darknet:
         _lib.check(_lib.load().yds_darknet_layer_shape(self._h, i, C.byref(c), C.byref(h), C.byref(w)))
         return c.value, h.value, w.value
 
+    def layer_format(self, i):
+        """Storage format of layer i's output as the graph currently runs it: 0 fp32, 1 split-fp16 record, 2 fp16 (half mode)."""
+        return int(_lib.load().yds_darknet_layer_format(self._h, i))
+
     def layer_output(self, i, batch=1):
         c, h, w = self.layer_shape(i)
         out = np.empty((batch, c, h, w), np.float32)
