@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line:
                       i+1 and the rest, every conv kernel has the chip to itself; "two-stream" = both passes share the CUs;
                       results are identical, pipeline.cpp explains the policy)
   value_f32_math      a short run of the same workload on the exact-fp32 MFMA kernels (dtype of `value` is f16x3)
+  value_half_mode     a short run with the detector in Darknet.half() (fp16 operands, 2-byte activations; not the metric)
   value_frame_by_frame  one frame in, one result out (batch_frames = 1, nothing enqueued ahead: the reference's own loop,
                       video_detect.py:124-157); value_frame_by_frame_lookahead1 hands the next frame over one step early
   roofline            dominant conv kernel vs its MFMA bound: HIP event pairs around every conv launch on the detector's
@@ -357,6 +358,19 @@ def main():
         del wl32
         lib.yds_set_conv_math(1)
 
+    # ---- Darknet.half() (ImageDetector(half=True), img_detect.py:49-50): single-term fp16 operands AND 2-byte activations in the
+    #      detector; fp16-class accuracy, never the metric - reported so that the half / default ratio comes from one box and one run
+    half_fps = None
+    if not args.no_extras and not args.half and math_name != "f32":
+        wlh = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=True)
+        wlh.to_device()
+        wlh.pipe.set_schedule(sched_arg)
+        kh = max(3, min(K, 20))
+        dth, _ = timed_steps(wlh, ranks, sync, kh, 3, 0, host_frames=False)
+        half_fps = ranks.total_frames(kh, B) / dth
+        del wlh
+        sync()
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:      # rank 0 at N = 1 only (bench contract)
         cpu = cpu_baseline("cfg3" if args.config == "cfg4" else args.config, args.cpu_frames)
@@ -377,6 +391,8 @@ def main():
             "value_with_upload_note": "same K steps, frames handed over as pinned host memory and uploaded inside the timed region (copy stream, three staging buffers, each batch announced two steps ahead like a decoder queue)",
             "value_other_schedule": other,
             "value_f32_math": None if f32_fps is None else round(f32_fps, 2),
+            "value_half_mode": None if half_fps is None else round(half_fps, 2),
+            "value_half_mode_note": "Darknet.half(): detector on single-term fp16 operands with 2-byte activations (the reference's ImageDetector(half=True)); fp16-class accuracy, not the metric",
             "value_frame_by_frame": None if fbf is None else round(fbf, 2),
             "value_frame_by_frame_lookahead1": None if fbf_ahead is None else round(fbf_ahead, 2),
             "value_frame_by_frame_note": "batch_frames = 1: one frame in, one result out, nothing enqueued ahead (video_detect.py:124-157); "

@@ -1,12 +1,13 @@
-# rocprofv3 kernel statistics of the default bench command (run on the GPU box): [MATH=f32] [PMC=1] tools/profile_bench.sh <cfg> <outdir>
+# rocprofv3 kernel statistics of the default bench command (run on the GPU box): [MATH=f32] [HALF=1] [PMC=1] tools/profile_bench.sh <cfg> <outdir>
 # pass 1 fills the conv tune cache so that the profiled pass holds no autotune launches.  MATH=f32 profiles the exact-fp32 leg
 # (bench.py --math f32: the arithmetic of value_f32_math / roofline_f32); output names then carry the suffix _f32.
 export TMPDIR=/tmp
 R=$PWD; cfg=${1:-cfg2}; out=$R/${2:-gpurun_out/prof}; mkdir -p $out
 math=${MATH:-f16x3}; sfx=""; [ "$math" = "f32" ] && sfx="_f32"
+half=""; [ "${HALF:-0}" = "1" ] && { half="--half"; sfx="_half"; }      # Darknet.half(): the 2-byte activation mode
 steps=${STEPS:-20}; [ "$math" = "f32" ] && steps=${STEPS:-8}
 export YDS_TUNE_CACHE=/tmp/yds_tune_$cfg$sfx.txt
-common="--config $cfg --math $math --no-extras --cpu-frames 0 --latency-steps 0"
+common="--config $cfg --math $math $half --no-extras --cpu-frames 0 --latency-steps 0"
 python bench.py $common --steps 5 --warmup 2 > $out/bench_${cfg}${sfx}_plain.json 2>$out/err1.log
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench_$cfg$sfx -- python $R/bench.py $common --steps $steps --warmup 3 > $out/bench_${cfg}${sfx}_under_rocprof.json 2>$out/err2.log

@@ -33,7 +33,8 @@ struct PatchRows {                                  // tile row -> flat output p
     }
 };
 
-template <int ACT>
+// HALF (Darknet.half(), round 4): single-term fp16 operands in both convolutions, hi halves only in the patch (as in conv_stem2.hip)
+template <int ACT, bool HALF>
 __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, ConvKernelArgs p3, int tiles_y, int tiles_x, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *w3 = smem, *xp = smem + W3_BYTES, *hp = smem + W3_BYTES + XP_BYTES;
@@ -104,10 +105,12 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
                 const int row = (sb >> 1) * PPIX + pr, sw = (row >> 1) & 7;
                 const char *ap = xp + row * 128;
                 const h8 xh = *reinterpret_cast<const h8 *>(ap + (((2 * (sb & 1) + kb) ^ sw) << 4));
-                const h8 xl = *reinterpret_cast<const h8 *>(ap + (((4 + 2 * (sb & 1) + kb) ^ sw) << 4));
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[sb], xh, c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[sb], xl, c2, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[sb], xh, c2, 0, 0, 0);
+                if (!HALF) {
+                    const h8 xl = *reinterpret_cast<const h8 *>(ap + (((4 + 2 * (sb & 1) + kb) ^ sw) << 4));
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2h[sb], xl, c2, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w2l[sb], xh, c2, 0, 0, 0);
+                }
             }
             const int ry = pr / PC, rc = pr - ry * PC;
             const bool inside = (unsigned)(oy0 - 1 + ry) < (unsigned)H && (unsigned)(ox0 - 1 + rc) < (unsigned)W;
@@ -118,14 +121,19 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int e = g * 4 + c;
-                    const float o = (c1[e] + c2[e] * (1.f / LO_SCALE)) * (1.f / A_SCALE) + bias2[e];
+                    const float o = (HALF ? c1[e] : c1[e] + c2[e] * (1.f / LO_SCALE)) * (1.f / A_SCALE) + bias2[e];
                     v[c] = inside ? apply_act<ACT>(o) : 0.f;      // the 3x3 zero-pads h
                 }
                 h16x4 hi, lo;
-                h16_encode4(v, hi, lo);
+                if (HALF) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) hi[c] = (_Float16)(v[c] * A_SCALE);
+                } else {
+                    h16_encode4(v, hi, lo);
+                }
                 if (pix < PPIX) {
                     *reinterpret_cast<h16x4 *>(hp + pr * 128 + ((g ^ sw) << 4) + kb * 8) = hi;
-                    *reinterpret_cast<h16x4 *>(hp + pr * 128 + (((4 + g) ^ sw) << 4) + kb * 8) = lo;
+                    if (!HALF) *reinterpret_cast<h16x4 *>(hp + pr * 128 + (((4 + g) ^ sw) << 4) + kb * 8) = lo;
                 }
             }
         }
@@ -142,28 +150,30 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const h8 ah = *reinterpret_cast<const h8 *>(ap + (((2 * s + kb) ^ jsw) << 4));
-                const h8 al = *reinterpret_cast<const h8 *>(ap + (((4 + 2 * s + kb) ^ jsw) << 4));
                 const h8 bh = *reinterpret_cast<const h8 *>(bp + (((2 * s + kb) ^ wsw) << 4));
-                const h8 bl = *reinterpret_cast<const h8 *>(bp + (((4 + 2 * s + kb) ^ wsw) << 4));
                 acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[0][0], 0, 0, 0);
-                acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[0][0], 0, 0, 0);
-                acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[0][0], 0, 0, 0);
+                if (!HALF) {
+                    const h8 al = *reinterpret_cast<const h8 *>(ap + (((4 + 2 * s + kb) ^ jsw) << 4));
+                    const h8 bl = *reinterpret_cast<const h8 *>(bp + (((4 + 2 * s + kb) ^ wsw) << 4));
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[0][0], 0, 0, 0);
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[0][0], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[0][0][e] = (acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
+        for (int e = 0; e < 16; ++e) acc1[0][0][e] = (HALF ? acc1[0][0][e] : acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
         // the staging area (32 x 68 floats) lives in the input patch, which phase A is done with
         conv_epilogue_rows<BM, BN, WM, WN, ACT, RES_AFTER_ACT, 1, 1, NT, PatchRows>(p3, acc1, reinterpret_cast<float *>(xp),
                                                                                      PatchRows{img, oy0, ox0, H, W}, 0, tid);
     }
 }
 
-template <int ACT> void launch_inst(const ConvKernelArgs &k2, const ConvKernelArgs &k3, hipStream_t s) {
+template <int ACT, bool HALF> void launch_inst(const ConvKernelArgs &k2, const ConvKernelArgs &k3, hipStream_t s) {
     static_assert((BM / WM) * (BN + 4) * 4 <= XP_BYTES, "epilogue staging must fit the input patch");
     const int n_img = k2.M / (k2.H * k2.W);
     const int tiles_y = (k2.H + TH - 1) / TH, tiles_x = (k2.W + TW - 1) / TW, n_tiles = n_img * tiles_y * tiles_x;
     static bool attr_set = false;
-    auto kern = conv_block1_f16x3<ACT>;
+    auto kern = conv_block1_f16x3<ACT, HALF>;
     if (!attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
@@ -184,8 +194,9 @@ bool conv_block1_applicable(const ConvKernelArgs &k2, const ConvKernelArgs &k3) 
 // k2 / k3: the two layers' own arguments (both .w = their pre-split f16x3 weights); k2's output tensor is never written
 void launch_conv_block1(const ConvKernelArgs &k2, const ConvKernelArgs &k3, hipStream_t s) {
     if (!conv_block1_applicable(k2, k3)) fail("conv: the fused residual block takes conv1x1 64->32 + conv3x3 32->64 + shortcut to the block input");
-    if (k2.act == ACT_LEAKY) launch_inst<ACT_LEAKY>(k2, k3, s);
-    else launch_inst<ACT_MISH>(k2, k3, s);
+    const bool half = k3.terms == 1;                             // Darknet.half(): single-term instantiation
+    if (k2.act == ACT_LEAKY) { if (half) launch_inst<ACT_LEAKY, true>(k2, k3, s); else launch_inst<ACT_LEAKY, false>(k2, k3, s); }
+    else { if (half) launch_inst<ACT_MISH, true>(k2, k3, s); else launch_inst<ACT_MISH, false>(k2, k3, s); }
 }
 
 }  // namespace yds

@@ -51,7 +51,9 @@ __device__ __forceinline__ int patch_row(int ry, int rc) {      // LDS row of la
     return (rc & 1) ? ODD_BASE + ry * ODD_COLS + (rc >> 1) : ry * EVEN_COLS + (rc >> 1);
 }
 
-template <int ACT0, int ACT1>
+// HALF (Darknet.half(), round 4): single-term fp16 operands in both layers - one MFMA per product block instead of three, the
+// patch rows carry hi halves only (no lo encode in phase A: 7 instead of 14 vector instructions per layer-0 value).
+template <int ACT0, int ACT1, bool HALF>
 __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, ConvKernelArgs p1, int tiles_y, int tiles_x, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *wreg = smem, *patch = smem + W_BYTES;
@@ -140,8 +142,10 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
                     xl.q[u] = px4.h[1];
                 }
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h[sb], xh.v, c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h[sb], xl.v, c2, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l[sb], xh.v, c2, 0, 0, 0);
+                if (!HALF) {
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h[sb], xl.v, c2, 0, 0, 0);
+                    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l[sb], xh.v, c2, 0, 0, 0);
+                }
             }
             // this lane: pixel `pix`, channels (e & 3) + 8 (e >> 2) + 4 kb0 -> four 8-byte pieces of hi and of lo
             const bool inside = pix < PATCH_ROWS && (unsigned)(ly0 + ry) < (unsigned)p0.H && (unsigned)(lx0 + rc) < (unsigned)p0.W;
@@ -152,14 +156,19 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int e = g * 4 + c;
-                    const float o = (c1[e] + c2[e] * (1.f / LO_SCALE)) * (1.f / A_SCALE) + bias0[e];
+                    const float o = (HALF ? c1[e] : c1[e] + c2[e] * (1.f / LO_SCALE)) * (1.f / A_SCALE) + bias0[e];
                     v[c] = inside ? apply_act<ACT0>(o) : 0.f;     // layer 1 zero-pads layer 0's output
                 }
                 h16x4 hi, lo;
-                h16_encode4(v, hi, lo);
+                if (HALF) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) hi[c] = (_Float16)(v[c] * A_SCALE);
+                } else {
+                    h16_encode4(v, hi, lo);
+                }
                 if (pix < PATCH_ROWS) {
                     *reinterpret_cast<h16x4 *>(patch + j * 128 + ((g ^ jsw) << 4) + kb0 * 8) = hi;          // chunk g: channels 8g .. 8g+7
-                    *reinterpret_cast<h16x4 *>(patch + j * 128 + (((4 + g) ^ jsw) << 4) + kb0 * 8) = lo;
+                    if (!HALF) *reinterpret_cast<h16x4 *>(patch + j * 128 + (((4 + g) ^ jsw) << 4) + kb0 * 8) = lo;
                 }
             }
         }
@@ -177,28 +186,30 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const h8 ah = *reinterpret_cast<const h8 *>(ap + (((2 * s + kb) ^ jsw) << 4));
-                const h8 al = *reinterpret_cast<const h8 *>(ap + (((4 + 2 * s + kb) ^ jsw) << 4));
                 const h8 bh = *reinterpret_cast<const h8 *>(bp + (((2 * s + kb) ^ wsw) << 4));
-                const h8 bl = *reinterpret_cast<const h8 *>(bp + (((4 + 2 * s + kb) ^ wsw) << 4));
                 acc1[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[0][0], 0, 0, 0);
-                acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[0][0], 0, 0, 0);
-                acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[0][0], 0, 0, 0);
+                if (!HALF) {
+                    const h8 al = *reinterpret_cast<const h8 *>(ap + (((4 + 2 * s + kb) ^ jsw) << 4));
+                    const h8 bl = *reinterpret_cast<const h8 *>(bp + (((4 + 2 * s + kb) ^ wsw) << 4));
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc2[0][0], 0, 0, 0);
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc2[0][0], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[0][0][e] = (acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
+        for (int e = 0; e < 16; ++e) acc1[0][0][e] = (HALF ? acc1[0][0][e] : acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
         // the staging area (32 x 68 floats) lives in the RGB tile, which phase A is done with
         conv_epilogue_rows<BM, BN, WM, WN, ACT1, RES_NONE, 1, 1, NT, StemRows>(p1, acc1, reinterpret_cast<float *>(rgb),
                                                                                  StemRows{img, oy0, ox0, p1.Ho, p1.Wo}, 0, tid);
     }
 }
 
-template <int ACT0, int ACT1> void launch_inst(const ConvKernelArgs &k0, const ConvKernelArgs &k1, hipStream_t s) {
+template <int ACT0, int ACT1, bool HALF> void launch_inst(const ConvKernelArgs &k0, const ConvKernelArgs &k1, hipStream_t s) {
     static_assert((BM / WM) * (BN + 4) * 4 <= RGB_BYTES, "epilogue staging must fit the RGB tile");
     const int n_img = k0.M / (k0.H * k0.W);
     const int tiles_y = (k1.Ho + TH - 1) / TH, tiles_x = (k1.Wo + TW - 1) / TW, n_tiles = n_img * tiles_y * tiles_x;
     static bool attr_set = false;
-    auto kern = conv_stem2_f16x3<ACT0, ACT1>;
+    auto kern = conv_stem2_f16x3<ACT0, ACT1, HALF>;
     if (!attr_set) {
         YDS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
         attr_set = true;
@@ -218,8 +229,9 @@ bool conv_stem2_applicable(const ConvKernelArgs &k0, const ConvKernelArgs &k1) {
 // k0 / k1: the two layers' own arguments (k1.w = its pre-split f16x3 weights); k0's output tensor is never written
 void launch_conv_stem2(const ConvKernelArgs &k0, const ConvKernelArgs &k1, hipStream_t s) {
     if (!conv_stem2_applicable(k0, k1)) fail("conv: the fused stem takes a 3x3/s1 RGB->32 conv followed by a 3x3/s2 32->64 conv");
-    if (k0.act == ACT_LEAKY) launch_inst<ACT_LEAKY, ACT_LEAKY>(k0, k1, s);
-    else launch_inst<ACT_MISH, ACT_MISH>(k0, k1, s);
+    const bool half = k1.terms == 1;                             // Darknet.half(): single-term instantiation
+    if (k0.act == ACT_LEAKY) { if (half) launch_inst<ACT_LEAKY, ACT_LEAKY, true>(k0, k1, s); else launch_inst<ACT_LEAKY, ACT_LEAKY, false>(k0, k1, s); }
+    else { if (half) launch_inst<ACT_MISH, ACT_MISH, true>(k0, k1, s); else launch_inst<ACT_MISH, ACT_MISH, false>(k0, k1, s); }
 }
 
 }  // namespace yds

@@ -302,7 +302,9 @@ void conv_win_clock(unsigned long long *cycles_ticks, bool reset) {
 bool conv_win_applicable(const ConvKernelArgs &k) {
     const bool presplit = (k.fmt_x == FMT_H16 && k.Cin % 32 == 0) || (k.fmt_x == FMT_F16 && k.terms == 1 && k.Cin % 64 == 0);
     if (!(k.ksize == 3 && k.stride == 1 && k.pad == 1 && presplit && k.H == k.Ho && k.W == k.Wo)) return false;
-    const int wrows = window_rows(k.W), nbuf = k.Cin == 32 ? 1 : 2;
+    // (half mode runs 64 channels per K step - launch_conv_win below - so a 64-channel layer is a single group there)
+    const bool wide_step = k.terms == 1 && k.Cin % 64 == 0 && (k.fmt_x == FMT_F16 || !getenv("YDS_HALF_NARROW"));
+    const int wrows = window_rows(k.W), nbuf = k.Cin == (wide_step ? 64 : 32) ? 1 : 2;
     // several channel groups: the next group's window is fetched by at most APW instructions per wave while this one is
     // consumed (two buffers); a single group needs one buffer only, which admits much wider images
     if (nbuf == 2 && wrows > MAX_WROWS) return false;
