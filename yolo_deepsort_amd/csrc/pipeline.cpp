@@ -243,11 +243,14 @@ public:
         //  two-stream form on yolov4: 1456 -> 1415 then.)  With the frames uploaded inside the step (yds_pipeline_step_host) the
         // serialized form LOSES 4 % (1469-1508 -> 1426-1436: +1.3 ms per step on the detector's stream that neither the start time of
         // the copy nor the result read-back explains - open), so that entry keeps two streams.
-        // Policy: serialize from 256 crops per batch when the frames are already in HBM.  yds_pipeline_set_schedule /
-        // YDS_PIPE_SERIAL=<crops> force a threshold for either entry, -1 = never.
+        // A detector in half mode keeps two streams as well: its pass is half as long, the (default-arithmetic) ReID pass is 40 % of
+        // the step, and its kernels are no longer power bound - running beside the ReID network's gains 3.5 % there (cfg2 --half,
+        // alternating runs on one box: 2210-2214 serialized, 2287-2295 two-stream).
+        // Policy: serialize from 256 crops per batch when the frames are already in HBM and the detector runs the default arithmetic.
+        // yds_pipeline_set_schedule / YDS_PIPE_SERIAL=<crops> force a threshold for either entry, -1 = never.
         const int serial_min = schedule_min_crops != INT_MIN ? schedule_min_crops
                                : getenv("YDS_PIPE_SERIAL")  ? atoi(getenv("YDS_PIPE_SERIAL"))
-                               : (!uploaded ? 256 : -1);
+                               : (!uploaded && !net->half_mode ? 256 : -1);
         int next_slot = -1;
         bool next_head_only = false;
         auto launch_next = [&](bool head_only) {                    // detector (+ NMS) of the next batch goes in flight
