@@ -50,6 +50,7 @@ void *yds_dev_alloc(size_t nbytes);
 int yds_dev_free(void *dev);
 int yds_memcpy_h2d(void *dst_dev, const void *src_host, size_t nbytes);
 int yds_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes);
+int yds_memcpy_d2d(void *dst_dev, const void *src_dev, size_t nbytes);   /* synchronous, like the two above */
 int yds_device_sync(void);
 
 /* ---- detector: Darknet(cfg).forward + YOLO decode --------------------------------------

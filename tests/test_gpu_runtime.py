@@ -273,3 +273,55 @@ def test_single_stream_mode_two_ranks_equals_one_process(tmp_path):
         assert np.array_equal(res[2][f"f{t}"], res[1][f"f{t}"]), t
         rows += int((res[1][f"f{t}"][:, 4] >= 0).sum())
     assert rows > 0
+
+
+def test_single_stream_device_exchange_world_of_one():
+    """Round 4: the single-stream mode with the embeddings kept in HBM - feature rows staged per frame in a device block, all-gathered
+    device to device over RCCL (a world of one is all this box can form) and read by the tracker from the gathered buffer - gives
+    the rows of the host-block form, for rounds of 1 and of 3 frames per rank."""
+    import ctypes as C
+    import numpy as np
+    from yolo_deepsort_amd import cfgs, synth
+    from yolo_deepsort_amd.dist import Ranks
+    from yolo_deepsort_amd.models import Darknet
+    from yolo_deepsort_amd.detect import ImageDetector
+    from yolo_deepsort_amd.deep_sort import DeepSort
+    from yolo_deepsort_amd.single_stream import SingleStream
+    import tempfile
+    _lib.init()
+    lib = _lib.load()
+    cfg = cfgs.cfg_text("yolov3-tiny", 416, 416)
+    net = Darknet(None, img_size=(416, 416), cfg_text=cfg)
+    net.load_darknet_weights(None, blob=synth.darknet_weights_blob(cfg, 0, 1.0))
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+        names = f.name
+    det = ImageDetector(net, names, thres=0.5, nms_thres=0.4)
+    scene = synth.PersonScene(6, frame_hw=(270, 480), seed=3, occlude_frac=0.0)
+    frames = [scene.frame(t) for t in range(8)]
+
+    def tracker():
+        return DeepSort(synth.reid_state_dict(0), use_cuda=True, max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
+
+    def rows(o):
+        return [None if x is None else np.asarray(x, np.int32).reshape(-1, 6) for x in o]
+
+    ranks = Ranks("gloo")                                         # no launcher: one rank
+    want = rows(SingleStream.from_components(ranks, det, tracker(), class_mask=[0, 2, 4], device=False).run(frames))
+    assert sum(len(x) for x in want if x is not None) > 0
+    ident = (C.c_char * 128)()
+    _lib.check(lib.yds_comm_unique_id(ident))
+    ranks.comm = _lib.check_ptr(lib.yds_comm_create(ident, 1, 0))
+    try:
+        for B in (1, 3):
+            S = SingleStream.from_components(ranks, det, tracker(), class_mask=[0, 2, 4], frames_per_rank=B, device=True)
+            assert S.on_device
+            got = rows(S.run(frames))
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert (a is None and b is None) or np.array_equal(a, b)
+            assert (len(frames) + B - 1) // B <= S.exchanges <= (len(frames) + B - 1) // B + 2     # one per round (+ a repeat when the block grows)
+    finally:
+        lib.yds_comm_destroy(ranks.comm)
+        ranks.comm = None
+        os.unlink(names)

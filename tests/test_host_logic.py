@@ -464,6 +464,15 @@ if r.rank == 0:
 else:
     assert out == [] and seen == []
 assert S.cap == 128                                             # grown alike on both ranks
+# round 4: rounds of B frames per rank (rank r owns frames base + r * B .. + B): one exchange per N * B frames, same results in frame order
+seen2 = []
+def track2(tlwh, payload, feats):
+    seen2.append((tlwh.shape, payload.tolist(), float(feats.sum())))
+    return ("rows", len(tlwh))
+S2 = ss.SingleStream(r, detect, track2, frames_per_rank=2)
+out2 = S2.run(frames)
+assert out2 == out and seen2 == seen and not S2.on_device
+assert S2.exchanges == 3 and S.exchanges == 5                   # 7 frames: 2 rounds of 4 (+ 1 repeat for the growth) against 4 rounds of 2 (+ 1)
 r.shutdown()
 ''' % ROOT
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:

@@ -40,6 +40,7 @@ SIGNATURES = {
     "yds_dev_free": (_I, [_P]),
     "yds_memcpy_h2d": (_I, [_P, _P, _SZ]),
     "yds_memcpy_d2h": (_I, [_P, _P, _SZ]),
+    "yds_memcpy_d2d": (_I, [_P, _P, _SZ]),
     "yds_device_sync": (_I, []),
     "yds_darknet_create": (_P, [C.c_char_p, _I, _I, _I]),
     "yds_darknet_destroy": (None, [_P]),

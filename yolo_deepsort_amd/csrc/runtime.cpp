@@ -142,6 +142,12 @@ int yds_memcpy_d2h(void *dst_host, const void *src_dev, size_t nbytes) {
     YDS_API_END
 }
 
+int yds_memcpy_d2d(void *dst_dev, const void *src_dev, size_t nbytes) {
+    YDS_API_BEGIN
+    YDS_HIP(hipMemcpy(dst_dev, src_dev, nbytes, hipMemcpyDeviceToDevice));
+    YDS_API_END
+}
+
 int yds_device_sync(void) {
     YDS_API_BEGIN
     YDS_HIP(hipDeviceSynchronize());
