@@ -479,3 +479,32 @@ def test_half_mode_yolov4_two_byte_activations():
     net.float()
     assert [net.layer_format(i) for i in range(n_layers)] == fmt_full
     assert np.array_equal(full, np.asarray(net(x)))
+
+
+@pytest.mark.parametrize("name", ["yolov3-tiny", "yolov4-tiny"])
+def test_half_mode_tiny_nets_mixed_formats(name):
+    """Darknet.half() on the tiny networks: narrow first layers (16 / 32 channels: they keep the 4-byte record), max-pool chains
+    incl. the zero-padded k2 s1 pool, grouped routes (yolov4-tiny: 32-channel halves of a 64-channel tensor - not 64-channel granular,
+    so those buffers stay H16 next to fp16 neighbours).  Same bounds as the big networks, against the default arithmetic."""
+    from yolo_deepsort_amd.models import Darknet
+    cfg = cfgs.cfg_text(name, 416, 416)
+    net = Darknet(None, img_size=(416, 416), batch_max=2, cfg_text=cfg)
+    net.load_darknet_weights(None, blob=synth.darknet_weights_blob(cfg, 2, -2.0))
+    x = np.random.RandomState(3).uniform(0, 1, (2, 3, 416, 416)).astype(F32)
+    full = np.asarray(net(x))
+    n_layers = len(net.module_defs)
+    fmt_full = [net.layer_format(i) for i in range(n_layers)]
+    net.half()
+    half = np.asarray(net(x))
+    fmt_half = [net.layer_format(i) for i in range(n_layers)]
+    assert 2 in fmt_half and 1 in fmt_half, fmt_half          # both formats live side by side
+    assert all(h == f or (f == 1 and h == 2) for f, h in zip(fmt_full, fmt_half))
+    e_p = np.abs(half[..., 4:] - full[..., 4:])
+    e_c = np.abs(half[..., :2] - full[..., :2])
+    e_s = np.abs(half[..., 2:4] - full[..., 2:4]) / np.abs(full[..., 2:4])
+    print("%s half mode vs default: prob abs err max %.2e | centre px max %.3f | size rel max %.2e" % (name, e_p.max(), e_c.max(), e_s.max()))
+    assert e_p.max() < 1.5e-2 and e_c.max() < 0.5 and e_s.max() < 5e-2
+    assert e_s.max() > 0                                        # a different arithmetic really ran
+    net.float()
+    assert [net.layer_format(i) for i in range(n_layers)] == fmt_full
+    assert np.array_equal(full, np.asarray(net(x)))
