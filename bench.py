@@ -360,16 +360,19 @@ def main():
 
     # ---- Darknet.half() (ImageDetector(half=True), img_detect.py:49-50): single-term fp16 operands AND 2-byte activations in the
     #      detector; fp16-class accuracy, never the metric - reported so that the half / default ratio comes from one box and one run
-    half_fps = None
+    half_fps, half_err = None, None
     if not args.no_extras and not args.half and math_name != "f32":
-        wlh = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=True)
-        wlh.to_device()
-        wlh.pipe.set_schedule(sched_arg)
-        kh = max(3, min(K, 20))
-        dth, _ = timed_steps(wlh, ranks, sync, kh, 3, 0, host_frames=False)
-        half_fps = ranks.total_frames(kh, B) / dth
-        del wlh
-        sync()
+        try:                                                       # (a side leg: its failure must not cost the line its metric)
+            wlh = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=True)
+            wlh.to_device()
+            wlh.pipe.set_schedule(sched_arg)
+            kh = max(3, min(K, 20))
+            dth, _ = timed_steps(wlh, ranks, sync, kh, 3, 0, host_frames=False)
+            half_fps = ranks.total_frames(kh, B) / dth
+            del wlh
+            sync()
+        except Exception as e:                                     # noqa: BLE001
+            half_err = f"{type(e).__name__}: {e}"[:300]
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:      # rank 0 at N = 1 only (bench contract)
@@ -392,6 +395,7 @@ def main():
             "value_other_schedule": other,
             "value_f32_math": None if f32_fps is None else round(f32_fps, 2),
             "value_half_mode": None if half_fps is None else round(half_fps, 2),
+            **({"value_half_mode_error": half_err} if half_err else {}),
             "value_half_mode_note": "Darknet.half(): detector on single-term fp16 operands with 2-byte activations (the reference's ImageDetector(half=True)); fp16-class accuracy, not the metric",
             "value_frame_by_frame": None if fbf is None else round(fbf, 2),
             "value_frame_by_frame_lookahead1": None if fbf_ahead is None else round(fbf_ahead, 2),
