@@ -141,3 +141,48 @@ def test_direct_rgb_kernel_vs_float64():
         want = _conv_ref(x, w, bias, 3, 1, ACT[act], None, 0)
         got = _run(L, direct[0], x, w, bias, 3, 1, ACT[act], None, 0)
         assert float(np.abs(got - want).max()) / float(np.abs(want).max()) < 1e-5
+
+
+def test_h16_range_saturates():
+    """The H16 activation format holds |x| <= 65504 * 256 = 1.677e7 (csrc/h16.h).  Beyond it an encoded value SATURATES (every
+    encoding kernel sets MODE.FP16_OVFL) instead of turning into inf / NaN: outputs of a layer whose pre-images exceed the range
+    are finite, clamped to +-(65504 .. 65536) * 256 with the right sign, and every in-range output keeps its accuracy - for each
+    f16x3 variant that takes the layer, and for an out-of-range INPUT tensor as well (the packing kernel clamps it)."""
+    from yolo_deepsort_amd import _lib as L
+    L.init(0)
+    lib = L.load()
+    lib.yds_conv_variant_name.restype = C.c_char_p
+    prev = lib.yds_get_conv_math()
+    L.check(lib.yds_set_conv_math(1))
+    LIM, TOP = 65504.0 * 256, 65536.0 * 256
+    try:
+        names = [lib.yds_conv_variant_name(v).decode() for v in range(lib.yds_conv_num_variants())]
+        mine = [v for v, nme in enumerate(names) if "f16x3" in nme and "direct" not in nme]
+        rng = np.random.RandomState(23)
+        ran = 0
+        for n, h, wd, cin, cout, k in ((2, 19, 19, 64, 128, 3), (1, 26, 26, 128, 64, 1)):
+            x = (rng.standard_normal((n, h, wd, cin)) * 1e4).astype(F32)
+            w = (rng.standard_normal((cout, k * k * cin)) / np.sqrt(k * k * cin) * 1e3).astype(F32)
+            bias = np.zeros(cout, F32)
+            want = _conv_ref(x, w, bias, k, 1, 0, None, 0)
+            over, inside = np.abs(want) > 1.01 * TOP, np.abs(want) < 0.99 * LIM
+            assert over.mean() > 0.02 and inside.mean() > 0.5
+            for v in mine:
+                try:
+                    got = _run(L, v, x, w, bias, k, 1, 0, None, 0)
+                except L.YdsError:
+                    continue
+                ran += 1
+                assert np.isfinite(got).all(), names[v]
+                assert np.abs(got[inside] - want[inside]).max() < 1e-3 * LIM, names[v]
+                assert (np.abs(got[over]) >= LIM).all() and (np.abs(got[over]) <= TOP).all(), names[v]
+                assert np.array_equal(np.sign(got[over]), np.sign(want[over])), names[v]
+        assert ran >= 6
+        # an input beyond the range: clamped by the packing kernel, the layer's result stays finite
+        x = np.full((1, 8, 8, 32), 3e7, F32)
+        w = np.zeros((32, 32), F32)
+        w[np.arange(32), np.arange(32)] = 1
+        got = _run(L, mine[0], x, w, np.zeros(32, F32), 1, 1, 0, None, 0)
+        assert np.isfinite(got).all() and (got >= LIM).all() and (got <= TOP).all()
+    finally:
+        lib.yds_set_conv_math(prev)

@@ -271,6 +271,40 @@ def test_tiny416_golden():
     _close(out, g["out"])
 
 
+def test_rectangular_input_and_the_scale_pairing_quirk():
+    """Darknet(img_size=(h, w)) with h != w (VERDICT r4 'missing' #3) against the reference's fixture: yolov3-tiny at (416, 608)
+    raw and through ImageDetector.detect on a 640x480 frame (resize to 608 wide x 416 high, NMS, resize_boxes with the (h, w)
+    pair), and the 44x64 net whose height / width ratios differ (8.8 against 8.0), where YOLOLayer's pairing of x and w with
+    the HEIGHT ratio (models.py:169-172,216; layers.hip yolo_decode_kernel) decides every box column."""
+    from oracle.gen_golden import QUIRK_CFG
+    from yolo_deepsort_amd.detect import ImageDetector
+    g = golden("darknet_rect")
+    net, ref = _nets(cfgs.cfg_text("yolov3-tiny", 608, 416), (416, 608), 0, -1.0)
+    x = np.random.RandomState(2).rand(1, 3, 416, 608).astype(F32)
+    y = np.asarray(net(x))
+    assert y.shape == (1, 3705, 85)
+    _close(y[0, :, :5], g["tiny_box"], msg="rect box columns")
+    _close(y.reshape(-1)[g["tiny_idx"]], g["tiny_val"], msg="rect sampled")
+    _close(y, ref(x), msg="rect oracle")
+    frame = np.random.RandomState(0).randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    import os
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+    det = np.asarray(ImageDetector(net, f.name, thres=0.5, nms_thres=0.4).detect(frame))
+    os.unlink(f.name)
+    want = g["tiny_det"]
+    assert det.shape == want.shape and np.array_equal(det[:, 5], want[:, 5])
+    _close(det, want, msg="rect detect")
+    q, qref = _nets(QUIRK_CFG, (44, 64), 5, -1.0, batch_max=2)
+    xq = np.random.RandomState(6).rand(2, 3, 44, 64).astype(F32)
+    yq = np.asarray(q(xq))
+    assert yq.shape == (2, 120, 7)
+    _close(yq, g["quirk_out"], msg="quirk golden")
+    _close(yq, qref(xq), msg="quirk oracle")
+    assert np.abs(yq[..., 0] * (8.0 / 8.8) - g["quirk_out"][..., 0]).max() > 1.0
+
+
 @pytest.mark.parametrize("name", ["yolov4-tiny"])
 def test_grouped_route_net_vs_oracle(name):
     net, ref = _nets(cfgs.cfg_text(name), 416, 1)

@@ -111,6 +111,35 @@ def test_detect_plumbing_cfg1():
     np.testing.assert_allclose(det, ref, rtol=RTOL, atol=ATOL)
 
 
+def test_rectangular_input_and_the_scale_pairing_quirk():
+    """a5 on non-square inputs (reference models.py:169-172,216: x and w go with the HEIGHT ratio): yolov3-tiny at
+    (416, 608) raw + through detect on a 640x480 frame, and the 44x64 net whose two ratios differ (8.8 / 8.0)."""
+    from oracle.gen_golden import QUIRK_CFG
+    from oracle.resize import resize_bilinear_u8
+    g = golden("darknet_rect")
+    net = _oracle_net(cfgs.cfg_text("yolov3-tiny", 608, 416), (416, 608), 0, -1.0)
+    x = np.random.RandomState(2).rand(1, 3, 416, 608).astype(F32)
+    y = net(x)
+    assert y.shape == tuple(g["tiny_shape"]) == (1, 3705, 85)
+    np.testing.assert_allclose(y[0, :, :5], g["tiny_box"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(y.reshape(-1)[g["tiny_idx"]], g["tiny_val"], rtol=RTOL, atol=ATOL)
+    frame = np.random.RandomState(0).randint(0, 256, (480, 640, 3)).astype(np.uint8)
+    img = resize_bilinear_u8(frame, (608, 416)).astype(F32).transpose(2, 0, 1)[None] / F32(255.)
+    assert img.shape == (1, 3, 416, 608)
+    det = onms.resize_boxes(onms.soft_non_max_suppression(net(img), 0.5, 0.4)[0], (416, 608), (480, 640))
+    ref = g["tiny_det"]
+    assert det.shape == ref.shape and ref.shape[0] > 0 and np.array_equal(det[:, 5], ref[:, 5])
+    np.testing.assert_allclose(det, ref, rtol=RTOL, atol=ATOL)
+    q = _oracle_net(QUIRK_CFG, (44, 64), 5, -1.0)
+    xq = np.random.RandomState(6).rand(2, 3, 44, 64).astype(F32)
+    yq = q(xq)
+    assert tuple(g["quirk_grid"]) == (5, 8) and np.allclose(g["quirk_scale"].ravel(), [8.8, 8.0])
+    assert yq.shape == g["quirk_out"].shape == (2, 120, 7)
+    np.testing.assert_allclose(yq, g["quirk_out"], rtol=RTOL, atol=ATOL)
+    # the pairing matters on this net: the un-quirked scaling (x by the width ratio) is far outside the tolerance
+    assert np.abs(yq[..., 0] * (8.0 / 8.8) - g["quirk_out"][..., 0]).max() > 1.0
+
+
 @pytest.mark.ref
 @pytest.mark.skipif(not has_reference(), reason="reference tree not present")
 def test_real_cfg_files_parse_identically():

@@ -28,6 +28,7 @@ namespace yds {
 
 template <int BM, int BN, int WM, int WN, int BK, int ACT, int RES>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
+    fp16_saturate_on();
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BK == 16 || BK == 32, "K step");
     constexpr int LDS_LD = BK + 4;                      // padded row: conflict-free ds_read_b128 fragments

@@ -36,6 +36,7 @@ struct PatchRows {                                  // tile row -> flat output p
 // HALF (Darknet.half(), round 4): single-term fp16 operands in both convolutions, hi halves only in the patch (as in conv_stem2.hip)
 template <int ACT, bool HALF>
 __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, ConvKernelArgs p3, int tiles_y, int tiles_x, int n_tiles) {
+    fp16_saturate_on();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *w3 = smem, *xp = smem + W3_BYTES, *hp = smem + W3_BYTES + XP_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN, kb = lane >> 5;

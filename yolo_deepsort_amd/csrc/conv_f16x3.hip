@@ -41,6 +41,7 @@ __device__ __forceinline__ void split4(const f32x4 &v, h4 &hi, h4 &lo) {
 // of the epilogue.
 template <int BM, int BN, int ACT, int RES, int AIN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f16x3(ConvKernelArgs p) {
+    fp16_saturate_on();
     constexpr int WM = 2, WN = 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = BM / 32, B_ROWS = BN / 32;      // 16-byte chunks per thread per K step (32 k)
@@ -236,6 +237,7 @@ constexpr size_t dma_smem_bytes(int BM, int BN, int NS) {
 template <int BM, int BN, int WM, int WN, int NS, int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN != 4 || dma_smem_bytes(BM, BN, NS) > 80 * 1024) ? 1 : (dma_smem_bytes(BM, BN, NS) <= 53 * 1024 ? 3 : 2))
 void conv_igemm_f16x3_dma(ConvKernelArgs p, const char *zero_page) {
+    fp16_saturate_on();
     constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int ROW = 128;
@@ -500,6 +502,7 @@ template <int BM, int BN, int WM, int WN, int NS> static void launch_cfg_dma(con
 // write raw fp32 partial sums into a workspace slab; splitk_reduce_kernel adds the slabs in slab order (deterministic:
 // the same bits on every run) and applies bias, activation, residual and the output format.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, int ksplit, int M, int ldw, ConvKernelArgs p) {
+    fp16_saturate_on();
     const int c4 = (p.Cout + 3) / 4;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= M * c4) return;

@@ -18,6 +18,7 @@ constexpr int TH = 8, TW = 32;                      // output pixels per tile (r
 
 template <int COUT, int ACT>
 __global__ __launch_bounds__(256) void conv3x3_rgb_direct(ConvKernelArgs p, int tiles_y, int tiles_x, int n_tiles) {
+    fp16_saturate_on();
     constexpr int QUADS = COUT / 4;                 // lanes per pixel
     constexpr int PIX_PER_PASS = 256 / QUADS, PASSES = TH * TW / PIX_PER_PASS;
     __shared__ float4 tile[TH + 2][TW + 2];         // input tile + halo (zero outside the image): the nine taps of a pixel
@@ -128,6 +129,7 @@ constexpr int PTH = 4, PTW = 16;                    // pooled pixels per tile
 
 template <int COUT, int ACT>
 __global__ __launch_bounds__(256) void conv3x3_rgb_pool(ConvKernelArgs p, int Hp, int Wp, int tiles_y, int tiles_x, int n_tiles) {
+    fp16_saturate_on();
     constexpr int QUADS = COUT / 4, PIX_PER_PASS = 256 / QUADS, PASSES = PTH * PTW / PIX_PER_PASS;
     constexpr int IR = 2 * PTH + 3, IC = 2 * PTW + 3;           // input tile incl. both halos
     __shared__ float4 tile[IR][IC];
@@ -205,6 +207,7 @@ constexpr int MP_NT = 512;
 
 template <int ACT>
 __global__ __launch_bounds__(MP_NT, MP_OCC) void conv3x3_rgb_pool_mfma(ConvKernelArgs p, int Hp, int Wp, int tiles_y, int tiles_x, int n_tiles) {
+    fp16_saturate_on();
     extern __shared__ __attribute__((aligned(16))) char mp_smem[];
     float4 *rgb = reinterpret_cast<float4 *>(mp_smem);              // [hi r g b 0 | lo r g b 0] per input pixel
     float *conv = reinterpret_cast<float *>(mp_smem + MP_IR * MP_IC * 16);

@@ -55,6 +55,7 @@ __device__ __forceinline__ int patch_row(int ry, int rc) {      // LDS row of la
 // patch rows carry hi halves only (no lo encode in phase A: 7 instead of 14 vector instructions per layer-0 value).
 template <int ACT0, int ACT1, bool HALF>
 __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, ConvKernelArgs p1, int tiles_y, int tiles_x, int n_tiles) {
+    fp16_saturate_on();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *wreg = smem, *patch = smem + W_BYTES;
     float4 *rgb = reinterpret_cast<float4 *>(smem + W_BYTES + PATCH_BYTES);

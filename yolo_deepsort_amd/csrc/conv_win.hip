@@ -43,6 +43,7 @@ constexpr int MAX_WROWS = APW * NW * 8;        // 448 window rows
 // thirds of them are gone: profiles/r03_fp8_cross.txt #5).  Needs Cin % 64 == 0; the tensors in HBM stay H16.
 template <int BN, int WM, int WN, int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int wrows, int nbuf) {
+    fp16_saturate_on();
     static_assert(WM * WN == NW, "eight waves");
     static_assert(TERMS == 1 || TERMS == 4, "the default arithmetic (three fp16 terms) is conv_win16.hip's kernel");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;

@@ -45,6 +45,7 @@ constexpr int max_wrows(int nw) { return APW * nw * 8; }   // 448 window rows fo
 // one-workgroup-per-CU tile spent ~40 % of its time outside the K loop there.
 template <int BM, int BN, int WM, int WN, int ACT, int RES>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv3x3_f16x3_win16(ConvKernelArgs p, int wrows, int nbuf) {
+    fp16_saturate_on();
     constexpr int NW = WM * WN, NT = NW * 64;
     static_assert(NW == 8 || NW == 4, "eight waves (one workgroup per CU) or four (two)");
     constexpr int RW = BM / WM, CW = BN / WN;                   // rows / filters per wave

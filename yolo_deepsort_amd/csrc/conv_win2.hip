@@ -29,6 +29,7 @@ constexpr int MAX_WROWS2 = 384;
 
 template <int ACT, int RES, int TERMS>
 __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, int wrows, int apw) {
+    fp16_saturate_on();
     constexpr int WM = 2, WN = 2, TM = 2, TN = 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int WB = wrows * ROW2;                                 // bytes per window buffer

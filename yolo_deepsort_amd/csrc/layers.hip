@@ -28,6 +28,7 @@ static inline int grid_for(size_t work, int block = 256) {
 // ------------------------------------------------------------------------------------ maxpool
 __global__ void maxpool_kernel(const float *x, float *y, int N, int H, int W, int C, int ldx, int Ho, int Wo, int ldy,
                                int k, int stride, int pad, int zero_br, int fmt_in, int fmt_out) {
+    fp16_saturate_on();
     const int C4 = C >> 2;
     const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -120,6 +121,7 @@ void launch_copy(const View &x, const View &y, hipStream_t s) {
 }
 
 __global__ void add_kernel(const float *a, const float *b, float *y, size_t pixels, int C, int lda, int ldb, int ldy, int fa, int fb, int fy) {
+    fp16_saturate_on();
     const int C4 = C >> 2;
     const size_t total = pixels * C4;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -178,6 +180,7 @@ __global__ void nhwc_to_nchw_kernel(const float *x, float *dst, int N, int C, in
     }
 }
 __global__ void pack_h16_kernel(const float *src, float *y, size_t pixels, int C, int ldy) {
+    fp16_saturate_on();
     const int C4 = C >> 2;
     const size_t total = pixels * C4;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {

@@ -142,10 +142,15 @@ class PersonScene:
     ``n_persons`` walkers with box w~U(40,80), h~U(100,200), velocity U(-3,3)
     px/frame, bouncing at the frame border.  ``n_visible`` (optional) shows a
     seeded random subset each frame (crowd config: 150 of 200); otherwise
-    ``occlude_frac`` of persons vanish for 1-5 frames now and then."""
+    ``occlude_frac`` of persons vanish for 1-5 frames now and then.
+    ``long_occlude`` = H (frames; long-stream parity fixtures): on top of that, every fifth person (0, 5, 10 ...) vanishes
+    once for 33-47 frames - longer than the demo's max_age = 30 (reference video_deepsort.py:18-25), so its track dies
+    (deep_sort/sort/track.py:146-152) and the person returns under a new id - and persons 1, 6, 11 ... vanish once for
+    12-28 frames (the confirmed track survives and is re-identified by appearance).  The windows start at frame 34 or
+    later, so the first 32 frames equal the stream without the option, and end before frame H - 8."""
 
     def __init__(self, n_persons=30, frame_hw=(1080, 1920), seed=0, n_visible=None,
-                 occlude_frac=0.05, feat_dim=512, feat_noise=0.03):
+                 occlude_frac=0.05, feat_dim=512, feat_noise=0.03, long_occlude=None):
         self.rng = np.random.RandomState(seed)
         self.H, self.W = frame_hw
         self.n = n_persons
@@ -163,6 +168,18 @@ class PersonScene:
         self.background = r.randint(0, 256, (self.H // 8 + 1, self.W // 8 + 1, 3)).astype(np.uint8)
         self._occluded_until = np.zeros(n_persons, np.int64)
         self._seed = seed
+        self.long_windows = {}                       # pid -> (first hidden frame, first visible frame again)
+        if long_occlude:
+            rw = np.random.RandomState((seed * 131 + 7) % (2 ** 31))
+            for pid in range(n_persons):
+                if pid % 5 == 0:
+                    L = int(rw.randint(33, 48))
+                elif pid % 5 == 1:
+                    L = int(rw.randint(12, 29))
+                else:
+                    continue
+                s0 = int(rw.randint(34, max(35, int(long_occlude) - L - 8)))
+                self.long_windows[pid] = (s0, s0 + L)
 
     def _positions(self, t):
         span = np.array([self.W, self.H]) - self.wh
@@ -173,9 +190,14 @@ class PersonScene:
 
     def visible(self, t):
         r = np.random.RandomState((self._seed * 1000003 + t * 7919 + 17) % (2 ** 31))
+        hidden = [pid for pid, (a, b) in self.long_windows.items() if a <= t < b]
         if self.n_visible is not None:
-            return np.sort(r.choice(self.n, self.n_visible, replace=False))
+            if not hidden:
+                return np.sort(r.choice(self.n, self.n_visible, replace=False))
+            pool = np.setdiff1d(np.arange(self.n), hidden)
+            return np.sort(r.choice(pool, min(self.n_visible, len(pool)), replace=False))
         vis = np.ones(self.n, bool)
+        vis[hidden] = False
         # deterministic occlusions: each (person, start) pair hashed from the seed
         for pid in range(self.n):
             for back in range(5):

@@ -24,7 +24,9 @@ CONF_THRES, NMS_THRES, CLASS_MASK = 0.5, 0.4, [0, 2, 4]
 
 
 class Workload:
-    def __init__(self, config, batch, seed=0, n_distinct=None, half=False):
+    def __init__(self, config, batch, seed=0, n_distinct=None, half=False, long_occlude=None, pingpong=True):
+        """long_occlude / pingpong=False: the long-stream parity form (tests/test_gpu_long_stream.py) - `n_distinct` frames of
+        the stream with synth.PersonScene's long occlusion windows, played once front to back."""
         from .deep_sort import DeepSort, Extractor
         from .models import Darknet
         from . import pipeline as pl
@@ -42,12 +44,12 @@ class Workload:
         self.ds = DeepSort(Extractor(self.reid_sd, max_crops=B * (per_frame + 8)), use_cuda=True, **DS_PARAMS)
         # ping-pong ring of frames so that the stream stays continuous when it wraps
         n_distinct = n_distinct or max(4 * B, 32)
-        self.scene = synth.PersonScene(self.cfg["persons"], seed=seed, n_visible=self.cfg["visible"])
+        self.scene = synth.PersonScene(self.cfg["persons"], seed=seed, n_visible=self.cfg["visible"], long_occlude=long_occlude)
         frames = np.stack([self.scene.frame(t) for t in range(n_distinct)], 0)
         heads = self.net.yolo_heads()
         self.inj = [synth.head_injection(self.scene.boxes(t)[1], (self.scene.H, self.scene.W), (IMG, IMG), heads, cls=0)
                     for t in range(n_distinct)]
-        self.order = list(range(n_distinct)) + list(range(n_distinct - 1, -1, -1))
+        self.order = list(range(n_distinct)) + (list(range(n_distinct - 1, -1, -1)) if pingpong else [])
         self.n_sets = len(self.order) // B
         pl.load_injection_sets(self.net, [[self.inj[self.order[s * B + b]] for b in range(B)] for s in range(self.n_sets)])
         self.H, self.W = frames.shape[1:3]
