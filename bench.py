@@ -13,16 +13,18 @@ Rank 0 prints ONE JSON line:
   value_other_schedule  the same K steps under the other stream schedule (config.schedule names the one `value` ran under:
                       "serialized" = the ReID pass of batch i is enqueued on the detector's stream between the first layers of pass
                       i+1 and the rest, every conv kernel has the chip to itself; "two-stream" = both passes share the CUs;
-                      results are identical, pipeline.cpp explains the policy)
+                      results are identical; the pipeline times both on its first steady-state steps and keeps the faster one -
+                      config.schedule_trial carries what it measured; those steps run as set-up before the W warm-up steps)
   value_f32_math      a short run of the same workload on the exact-fp32 MFMA kernels (dtype of `value` is f16x3)
   value_half_mode     a short run with the detector in Darknet.half() (fp16 operands, 2-byte activations; not the metric)
   value_frame_by_frame  one frame in, one result out (batch_frames = 1, nothing enqueued ahead: the reference's own loop,
                       video_detect.py:124-157); value_frame_by_frame_lookahead1 hands the next frame over one step early
   roofline            dominant conv kernel vs its MFMA bound: HIP event pairs around every conv launch on the detector's
                       stream, recorded (without host synchronisation) over a repeat of the SAME K timed steps - ReID and
-                      association streams live, next pass prefetched - so `achieved`, `avg_launch_us` and `frac` are the
-                      in-pipeline figures `value` was measured under (what a rocprofv3 --kernel-trace --stats summary of this
-                      command shows: profiles/); `frac_isolated` / `achieved_isolated` come from two non-prefetched steps (conv
+                      association streams live, next pass prefetched - under the SERIALIZED schedule (a diagnostic leg since
+                      round 5: every conv launch has the chip to itself there, so `achieved`, `avg_launch_us` and `frac` are the
+                      kernel's own in-pipeline figures whatever schedule the product picked for `value`; tools/profile_bench.sh
+                      profiles the same leg with rocprofv3: profiles/); `frac_isolated` / `achieved_isolated` come from two non-prefetched steps (conv
                       stream alone).  `all_conv_kernels` adds the per-launch attainable bound max(flops / MFMA peak,
                       bytes / 6.29 TB/s) so HBM-bound 1x1 layers are priced against the right roof.
   roofline_f32        the same record for the value_f32_math leg (exact fp32 MFMA kernels, the reference's own arithmetic)
@@ -157,6 +159,9 @@ def roofline_json(dom, allc, B, peak_note, traffic=None):
                                      attainable="sum over launches of max(flops / MFMA bound, algorithmic bytes / 6.29 TB/s)"))
     if traffic:
         rec.update(traffic)
+        if rec.get("traffic") and dom["avg_launch_us"]:
+            rec["hbm_gb_s"] = round(rec["traffic"] / dom["avg_launch_us"] / 1e3, 1)      # PMC bytes per launch / event-timed launch duration
+            rec["hbm_frac_of_8tb_s"] = round(rec["hbm_gb_s"] / 8000.0, 4)
     return rec
 
 
@@ -164,14 +169,25 @@ def committed_traffic(config, kernel, B, mode=""):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes over this command (tools/profile_bench.sh PMC=1): PMC
     counters cannot be read from inside this process."""
     cfg_key = "cfg3" if config == "cfg4" else config
-    for rnd in ("r04", "r03", "r02", "r01"):
+    out = None
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{cfg_key}{mode}.json")
         if os.path.exists(tpath) and json.load(open(tpath)).get("frames_per_step", 16) == B:
             rec = json.load(open(tpath))["kernels"].get(kernel)
             if rec:
-                return dict(traffic=round(rec["hbm_bytes_per_launch"]),
-                            traffic_unit="bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/" + os.path.basename(tpath) + ")")
-    return None
+                out = dict(traffic=round(rec["hbm_bytes_per_launch"]),
+                           traffic_unit="bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/" + os.path.basename(tpath) + ")")
+                break
+    # matrix-pipe utilisation of the same kernel from the committed SQ_VALU_MFMA_BUSY_CYCLES pass (tools/profile_bench.sh MFMA=1)
+    for rnd in ("r05",):
+        mpath = os.path.join(ROOT, "profiles", f"{rnd}_mfma_busy_{cfg_key}{mode}.json")
+        if os.path.exists(mpath):
+            rec = json.load(open(mpath))["kernels"].get(kernel)
+            if rec:
+                out = dict(out or {}, mfma_busy=rec["mfma_busy"],
+                           mfma_busy_note="SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles of the launch), rocprofv3 --pmc pass over this "
+                                          "command, profiles/" + os.path.basename(mpath))
+    return out
 
 
 def main():
@@ -189,7 +205,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--schedule", default="policy", choices=["policy", "serialized", "two-stream"],
                     help="ReID pass of batch i vs detector pass of batch i+1: serialized on one stream or sharing the CUs from two (yds_pipeline_set_schedule); "
-                         "policy = the library's own choice (serialized when the frames are resident in HBM: pipeline.cpp)")
+                         "policy = the library's own choice: both timed on this box at set-up, the faster one kept (pipeline.cpp Trial)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the upload-inclusive and f32-math legs")
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")
@@ -242,11 +258,29 @@ def main():
     def sync():
         _lib.check(lib.yds_device_sync())
 
+    def settle_schedule(w, first, host_frames):
+        """Set-up, like the conv autotuner's launches at plan time: the pipeline picks its stream schedule BY MEASUREMENT on the caller's
+        first steady-state steps (pipeline.cpp Trial: 4 steps serialized, 4 two-stream, the faster one kept).  These steps run here,
+        before the W warm-up steps, so that warm-up and timed region both run the settled schedule.  Returns (steps used, record)."""
+        n = 0
+        if args.schedule != "policy":
+            return 0, None
+        while w.pipe.schedule_trial(host_frames)["decided"] is None and n < 12:
+            w.step(first + n, prefetch=True, host_frames=host_frames, prefetch2=True)
+            n += 1
+        if n:                                                     # (leave nothing of the trial in flight across the clock start)
+            w.step(first + n, prefetch=False, host_frames=host_frames)
+            n += 1
+        rec = w.pipe.schedule_trial(host_frames)
+        tr = ranks.gather_objects(rec)
+        return n, tr
+
     # ---- the metric: frames resident in HBM
+    n_set, trial = settle_schedule(wl, 0, False)
     pl.conv_clock(reset=True)
     kept = [] if args.dump_rows else None
     own = {}
-    dt, n_out = timed_steps(wl, ranks, sync, K, W, 0, host_frames=False, keep=kept, own=own)     # n_out: rows of ALL streams (gathered on every rank)
+    dt, n_out = timed_steps(wl, ranks, sync, K, W, n_set, host_frames=False, keep=kept, own=own)     # n_out: rows of ALL streams (gathered on every rank)
     dt_own = own["dt"]
     clock_ghz, clock_ms = pl.conv_clock(reset=True)              # shader clock inside the window kernels over the K timed steps (+ warm-up)
     if kept is not None and rank == 0:
@@ -267,24 +301,36 @@ def main():
     # fp16 products, fp32 accumulation - the reference's fp32 class; f32 = v_mfma_f32_32x32x2_f32
 
     # ---- the same steps with the frames coming from pinned host memory (PCIe inside the timed region)
-    dt_up = None
+    dt_up, trial_up = None, None
+    base = n_set + W + K
     if not args.no_extras:
-        dt_up, _ = timed_steps(wl, ranks, sync, K, W, W + K, host_frames=True)
+        n_up, trial_up = settle_schedule(wl, base, True)
+        base += n_up
+        dt_up, _ = timed_steps(wl, ranks, sync, K, W, base, host_frames=True)
+        schedule_up = wl.pipe.last_schedule()
+        base += W + K
 
     # ---- the same K steps under the OTHER schedule (results are identical; the line carries both rates)
     other = None
     if not args.no_extras:
         wl.pipe.set_schedule(-1 if schedule == "serialized" else 0)
-        dt_o, _ = timed_steps(wl, ranks, sync, K, W, 2 * (W + K), host_frames=False)
+        dt_o, _ = timed_steps(wl, ranks, sync, K, W, base, host_frames=False)
         other = {"schedule": wl.pipe.last_schedule(), "value": round(ranks.total_frames(K, B) / dt_o, 2)}
         wl.pipe.set_schedule(sched_arg)
+        base += W + K
 
     roofline, variants = None, None
     if not args.no_roofline:
         # (every rank runs the leg - its steps contain the exchange step - rank 0 reports)
         f16x3 = lib.yds_get_conv_math() == 1 and not args.half
         peak = PEAK_F16_MFMA_TFLOPS / 3 if f16x3 else (PEAK_F16_MFMA_TFLOPS if args.half else PEAK_F32_MFMA_TFLOPS)
-        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, 3 * (W + K), peak)
+        # The per-kernel record is a DIAGNOSTIC leg under the serialized schedule whatever `value` ran under (round 5): there every conv
+        # launch has the chip to itself, so a launch's duration is the kernel's own; under two streams the ReID network's launches
+        # share the CUs and stretch every detector launch without the chip doing less (config.schedule / schedule_trial say what the
+        # product picked on this box and why).
+        wl.pipe.set_schedule(0)
+        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, base, peak)
+        wl.pipe.set_schedule(sched_arg)
         if rank == 0 and dom is not None:
             note = ("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
                     else ("dense fp16 MFMA" if args.half else "fp32-input MFMA, 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz"))
@@ -293,7 +339,8 @@ def main():
                 frac_of_fp32_mfma_peak=round(dom["achieved"] / PEAK_F32_MFMA_TFLOPS, 4),
                 # pure-MFMA loop on random fp16 data, sustained (power limited): profiles/r01_ablation_dma.txt #6
                 frac_of_measured_mfma_ceiling=round(dom["achieved"] / (MEASURED_F16_MFMA_TFLOPS / 3 if f16x3 else PEAK_F32_MFMA_TFLOPS), 4),
-                fps_with_conv_events=round(ranks.total_frames(K, B) / dt_ev, 2), schedule=schedule,
+                fps_with_conv_events=round(ranks.total_frames(K, B) / dt_ev, 2),
+                schedule="serialized (diagnostic leg: every conv launch has the chip to itself; `value` ran under config.schedule = %s)" % schedule,
                 # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
                 # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
                 pipeline_conv_frac=round(flops_frame * K * B / dt / 1e12 / peak, 4),
@@ -344,17 +391,21 @@ def main():
         wl32 = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base))
         wl32.to_device()
         wl32.pipe.set_schedule(sched_arg)
+        n32, trial32 = settle_schedule(wl32, 0, False)
         k32 = max(3, min(K, 10))                                  # (shorter runs under-read this mode: its first steps still ramp)
-        dt32, _ = timed_steps(wl32, ranks, sync, k32, 3, 0, host_frames=False)
+        dt32, _ = timed_steps(wl32, ranks, sync, k32, 3, n32, host_frames=False)
         f32_fps = ranks.total_frames(k32, B) / dt32
+        sched32 = wl32.pipe.last_schedule()
         if not args.no_roofline:
-            _, dom32, all32, _ = measure_roofline(wl32, ranks, sync, pl, k32, 3, k32 + 3, PEAK_F32_MFMA_TFLOPS)
+            wl32.pipe.set_schedule(0)
+            _, dom32, all32, _ = measure_roofline(wl32, ranks, sync, pl, k32, 3, n32 + k32 + 3, PEAK_F32_MFMA_TFLOPS)
             if rank == 0 and dom32 is not None:
                 roofline_f32 = roofline_json(dom32, all32, B, "fp32-input MFMA (v_mfma_f32_32x32x2_f32), 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz",
                                              committed_traffic(args.config, dom32["kernel"], B, "_f32"))
                 roofline_f32["pipeline_conv_frac"] = round(flops_frame * k32 * B / dt32 / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                 roofline_f32["value_f32_math"] = round(f32_fps, 2)
-                roofline_f32["schedule"] = wl32.pipe.last_schedule()
+                roofline_f32["schedule"] = "serialized (diagnostic leg); value_f32_math ran under " + sched32
+                roofline_f32["schedule_trial"] = trial32
         del wl32
         lib.yds_set_conv_math(1)
 
@@ -362,17 +413,27 @@ def main():
     #      detector; fp16-class accuracy, never the metric - reported so that the half / default ratio comes from one box and one run
     half_fps, half_err = None, None
     if not args.no_extras and not args.half and math_name != "f32":
-        try:                                                       # (a side leg: its failure must not cost the line its metric)
+        # A side leg: its failure must not cost the line its metric.  The part that can fail per rank (building the half-mode network: memory,
+        # a format check) runs first; the ranks then VOTE, and only if every rank built its workload do they enter timed_steps, whose
+        # barriers and gathers are collectives - a rank skipping them alone would leave its peers blocked.
+        wlh = None
+        try:
             wlh = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=True)
             wlh.to_device()
             wlh.pipe.set_schedule(sched_arg)
-            kh = max(3, min(K, 20))
-            dth, _ = timed_steps(wlh, ranks, sync, kh, 3, 0, host_frames=False)
-            half_fps = ranks.total_frames(kh, B) / dth
-            del wlh
-            sync()
         except Exception as e:                                     # noqa: BLE001
             half_err = f"{type(e).__name__}: {e}"[:300]
+            wlh = None
+        votes = ranks.gather_objects(half_err)
+        if all(v is None for v in votes):
+            nh, _ = settle_schedule(wlh, 0, False)
+            kh = max(3, min(K, 20))
+            dth, _ = timed_steps(wlh, ranks, sync, kh, 3, nh, host_frames=False)
+            half_fps = ranks.total_frames(kh, B) / dth
+        else:
+            half_err = "; ".join(f"rank {r}: {v}" for r, v in enumerate(votes) if v is not None)[:300]
+        del wlh
+        sync()
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:      # rank 0 at N = 1 only (bench contract)
@@ -388,9 +449,15 @@ def main():
             "config": {"workload": cfg["workload"], "frames_per_step": B, "streams": world, "frame": "1920x1080x3 u8",
                        "frames_in": "resident in HBM", "tracker_rows_out": n_out, "schedule": schedule, "parallelism": f"stream-per-gpu x{world}",
                        "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices],
-                       "rank_values": rank_values, **ranks.describe()},
+                       "rank_values": rank_values,
+                       "schedule_trial": None if trial is None else dict(
+                           note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds per 3 steps under either "
+                                "schedule on this box, per rank; `schedule` is what the timed steps then ran under",
+                           per_rank=trial, with_upload=trial_up, set_up_steps=n_set),
+                       **ranks.describe()},
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_with_upload is the PCIe-inclusive rate",
             "value_with_upload": None if dt_up is None else round(frames_total / dt_up, 2),
+            "value_with_upload_schedule": None if dt_up is None else schedule_up,
             "value_with_upload_note": "same K steps, frames handed over as pinned host memory and uploaded inside the timed region (copy stream, three staging buffers, each batch announced two steps ahead like a decoder queue)",
             "value_other_schedule": other,
             "value_f32_math": None if f32_fps is None else round(f32_fps, 2),

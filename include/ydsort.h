@@ -247,12 +247,17 @@ int yds_pipeline_set_next_injection(yds_pipe *, int set);
  * (no reference counterpart: video_detect.py:134-157 runs them one after the other on one frame; results do not depend on
  * the choice).  min_crops >= 0: from that many crops per batch the ReID pass is enqueued on the detector's stream, between
  * the first layers of the next pass and the rest (every conv kernel has the chip to itself); -1: always two streams sharing
- * the CUs; < -1: the built-in policy (serialize from 256 crops per batch when the frames are already in HBM, two streams for
- * yds_pipeline_step_host and for small batches; env YDS_PIPE_SERIAL overrides; measurements in pipeline.cpp).
- * yds_pipeline_last_schedule: 1 if the last step ran serialized, else 0. */
+ * the CUs; < -1: the built-in policy (round 5: BY MEASUREMENT - for ReID passes of >= 256 crops the pipeline times both schedules on
+ * the caller's first steady-state steps, 4 steps each, and keeps the faster one; one decision for yds_pipeline_step, one for
+ * yds_pipeline_step_host; two streams for smaller passes; env YDS_PIPE_SERIAL overrides; pipeline.cpp `Trial`).
+ * yds_pipeline_last_schedule: 1 if the last step ran serialized, else 0.
+ * yds_pipeline_schedule_trial: what the trial of an entry (uploaded = 0: yds_pipeline_step, 1: yds_pipeline_step_host) measured -
+ * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds per group of 3 steps under either schedule. */
 int yds_pipeline_set_schedule(yds_pipe *, int min_crops);
 int yds_pipeline_last_schedule(yds_pipe *);
-/* last step, microseconds: resize (device), detector (device), host wall until NMS results, ReID, association */
+int yds_pipeline_schedule_trial(yds_pipe *, int uploaded, int *decided, double *serialized_s, double *two_stream_s);
+/* last step, microseconds: resize (device), detector (device: the detector pass alone - a ReID pass the serialized schedule puts
+ * between its first layers and the rest is timed by its own event pair and subtracted), host wall until NMS results, ReID, association */
 int yds_pipeline_stage_us(yds_pipe *, float *us5);
 /* Per tile-variant totals of the implicit-GEMM conv kernel (yds_conv_num_variants instantiations):
  * duration in us, launch count and algorithmic flops, measured with HIP events recorded around every

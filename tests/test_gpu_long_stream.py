@@ -2,7 +2,8 @@
 cfg3 / cfg5 streams - with synth.PersonScene's long occlusion windows, so that confirmed tracks die of max_age = 30
 (reference deep_sort/sort/track.py:146-152), persons return under new ids, tracks are re-identified after 12-28 hidden
 frames and the galleries run into nn_budget = 30 (nn_matching.py:152-155) - through the very Workload object bench.py
-times (32 frames per step, next pass prefetched, both stream schedules), against rows the REFERENCE produced on the same
+times (32 frames per step, next pass prefetched; the library's own schedule policy - which times both stream schedules on these very
+steps and switches mid-stream - and each schedule forced), against rows the REFERENCE produced on the same
 frames (oracle/gen_golden.py gen_long_stream: the body of video_detect.py:134-157 with the real Extractor).
 
 Exact: None-ness, row counts, track ids and classes of every frame; the track list (ids, states, time_since_update) after
@@ -65,15 +66,27 @@ def _run(config, schedule):
         assert np.array_equal(st["state"], g["state"][sl]), t
         assert np.array_equal(st["tsu"], g["time_since_update"][sl]), t
     assert total > 0 and off / total < 5e-3, (off, total)
-    return wl.pipe.last_schedule(), g
+    return wl.pipe.last_schedule(), g, wl.pipe.schedule_trial()
 
 
-@pytest.mark.parametrize("config,schedule,name", [("cfg2", None, "serialized"), ("cfg2", -1, "two-stream"),
-                                                  ("cfg3", None, "serialized"), ("cfg3", -1, "two-stream"),
-                                                  ("cfg5", None, "serialized"), ("cfg5", -1, "two-stream")])
+@pytest.mark.parametrize("config,schedule,name", [("cfg2", None, "policy"), ("cfg2", -1, "two-stream"), ("cfg2", 256, "serialized"),
+                                                  ("cfg3", None, "policy"), ("cfg3", -1, "two-stream"),
+                                                  ("cfg5", None, "policy"), ("cfg5", 256, "serialized")])
 def test_long_stream_ids_bit_exact_vs_reference(config, schedule, name):
-    ran, g = _run(config, schedule)
-    assert ran == name
+    ran, g, trial = _run(config, schedule)
+    if name == "policy":
+        # the pipeline timed both schedules on the stream's own steps (4 serialized, then two-stream: pipeline.cpp Trial) - so this run
+        # also crossed from one schedule to the other in the middle of the stream, with identical rows
+        n_steady = int(g["n_frames"]) // B - 1
+        if n_steady >= 8:
+            assert trial["decided"] in ("serialized", "two-stream") and trial["serialized_s"] > 0 and trial["two_stream_s"] > 0, trial
+            assert ran == trial["decided"]
+        else:
+            assert trial["decided"] is None, trial
+            if n_steady >= 5:                    # cfg2: steps 0-3 serialized, 4-7 two-stream
+                assert trial["serialized_s"] > 0 and ran == "two-stream", (trial, ran)
+    else:
+        assert ran == name and trial["decided"] is None
     deaths, births, at_budget = _events(g)
     # the stream really contains what the 32-frame fixtures cannot: deaths of confirmed tracks, re-births, full galleries
     assert deaths >= 3 and births >= 3 and at_budget >= 20, (deaths, births, at_budget)

@@ -105,6 +105,41 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
     assert total == line["config"]["tracker_rows_out"] and total > 0                            # rank 0 holds BOTH streams' rows
 
 
+def test_eight_rank_bench_path_on_one_gpu(tmp_path):
+    """De-risks the driver's 8-GPU line on the 1-GPU box (VERDICT r4 'next' #7): `bench.py --gpus 8 --config cfg4` as EIGHT processes under
+    torch.distributed.run - the 8-way rendezvous, eight concurrent plan-time autotunes (sharing one YDS_TUNE_CACHE file: concurrent
+    appends and reads), eight schedule trials, the exchange step over eight blocks per frame with an exchange block that starts
+    too small (YDS_EXCHANGE_ROWS=8: it has to grow in the first steps) - all ranks bound to GPU 0, gloo as transport (RCCL refuses
+    ranks sharing a device; the real run has one GPU per rank and RCCL).  Every stream's rows, as gathered on rank 0, must equal a
+    single-rank run of that seed bit for bit (reference: one DeepSort.clone() per stream, deep_sort/deep_sort.py:41-44)."""
+    import numpy as np
+    N = 8
+    cache = str(tmp_path / "tune.txt")
+    env = dict(os.environ, YDS_DEVICE="0", YDS_DIST_BACKEND="gloo", YDS_TUNE_CACHE=cache, YDS_EXCHANGE_ROWS="8")
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={N}", "--master-addr", "127.0.0.1", "--master-port", "29591"]
+    allp = str(tmp_path / "all.npz")
+    args = ["--config", "cfg4", "--steps", "3", "--warmup", "1", "--batch", "4"]
+    line = _bench(tmp_path, ["--gpus", str(N)] + args + ["--dump-rows", allp], env, launcher)
+    c = line["config"]
+    assert line["n_gpus"] == N and c["streams"] == N and line["scaling"] == "weak" and line["value"] > 0
+    assert c["rank_devices"] == [0] * N and c["transport"] == "gloo" and len(c["rank_values"]) == N and all(v > 0 for v in c["rank_values"])
+    assert c["exchange_block_rows"] == 64, c["exchange_block_rows"]          # grew from 8 rows (a frame here has ~30) to the next multiple of 64
+    assert os.path.getsize(cache) > 0
+    g = np.load(allp)
+    total = 0
+    env1 = dict(os.environ, YDS_TUNE_CACHE=cache)                             # (the single-rank runs read the choices the eight wrote)
+    for seed in range(N):
+        one = str(tmp_path / f"one{seed}.npz")
+        _bench(tmp_path, ["--gpus", "1"] + args + ["--seed-base", str(seed), "--dump-rows", one], env1)
+        h = np.load(one)
+        keys = sorted(k for k in g.files if k.startswith(f"s{seed}_"))
+        assert keys and sorted(h.files) == sorted(k.replace(f"s{seed}_", "s0_") for k in keys), seed
+        for k in keys:
+            assert np.array_equal(g[k], h[k.replace(f"s{seed}_", "s0_")]), (seed, k)
+            total += int((g[k][:, 4] >= 0).sum())
+    assert total == c["tracker_rows_out"] and total > 0
+
+
 def test_rccl_failure_fails_the_multi_gpu_bench(tmp_path):
     """Two ranks on ONE device with the RCCL backend asked for (the default): both ranks pass the local preflight, rank 0 creates the
     id, both call ncclCommInitRank, RCCL refuses (duplicate GPU).  Every rank agrees on the outcome over the host group (no rank is

@@ -130,6 +130,7 @@ SIGNATURES = {
     "yds_pipeline_stage_us": (_I, [_P, _P]),
     "yds_pipeline_set_schedule": (_I, [_P, _I]),
     "yds_pipeline_last_schedule": (_I, [_P]),
+    "yds_pipeline_schedule_trial": (_I, [_P, _I, _P, _P, _P]),
     "yds_conv_timing": (_I, [_P, _I, _P, _P, _P]),
 }
 

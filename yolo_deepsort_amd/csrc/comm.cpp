@@ -210,12 +210,17 @@ int yds_comm_allgather_rows(yds_comm *c, const int32_t *out6_host, int cap, cons
                             int32_t *all_host, int *rows_needed) {
     YDS_API_BEGIN
     live(c);
+    // (rows_per_block and batch are protocol constants: the same on every rank, so this check fails on all of them alike)
     if (rows_per_block < 1) yds::fail("comm: rows_per_block must be positive");
     const int BLK = 1 + rows_per_block * 6;
+    constexpr int32_t BAD = INT32_MIN;             // header of a frame whose rank found its own input inconsistent
     std::vector<int32_t> blk((size_t)batch * BLK, 0);
+    int bad_frame = -1, bad_n = 0;
     for (int b = 0; b < batch; ++b) {
         const int n = counts_host[b];
-        if (n > cap) yds::fail("comm: frame %d announces %d rows, the caller's buffer holds %d", b, n, cap);
+        // A rank-LOCAL inconsistency must not keep this rank out of the collective (its peers would block in ncclAllGather for
+        // ever): it is announced in band, every rank sees it in the gathered headers and all of them fail together.
+        if (n > cap) { blk[(size_t)b * BLK] = BAD; if (bad_frame < 0) { bad_frame = b; bad_n = n; } continue; }
         blk[(size_t)b * BLK] = n > rows_per_block ? -(2 + n) : n;
         if (n > 0 && n <= rows_per_block) memcpy(&blk[(size_t)b * BLK + 1], out6_host + (size_t)b * cap * 6, (size_t)n * 6 * sizeof(int32_t));
     }
@@ -223,6 +228,11 @@ int yds_comm_allgather_rows(yds_comm *c, const int32_t *out6_host, int cap, cons
     int need = 0;
     for (size_t f = 0; f < (size_t)c->world * batch; ++f) {
         const int h = all_host[f * BLK];
+        if (h == BAD) {
+            const int r = (int)(f / batch);
+            if (r == c->rank && bad_frame >= 0) yds::fail("comm: frame %d announces %d rows, the caller's buffer holds %d", bad_frame, bad_n, cap);
+            yds::fail("comm: rank %d announced an inconsistent result block (frame %d); the exchange step failed on every rank", r, (int)(f % batch));
+        }
         need = std::max(need, h <= -2 ? -2 - h : std::max(h, 0));
     }
     if (rows_needed) *rows_needed = need;

@@ -219,6 +219,7 @@ public:
     int *boxes_pin[2] = {nullptr, nullptr};
     size_t boxes_pin_cap[2] = {0, 0};
     int boxes_pin_turn = 0;
+    hipStream_t sync_before_regrow = nullptr;   // set by the pipeline while a pass runs on another stream than the previous one
     std::map<int, std::pair<int, int>> tuned;   // conv index -> (D at measurement, measured tile variant)
     int tuned_math = -1;
     hipStream_t stream = nullptr;

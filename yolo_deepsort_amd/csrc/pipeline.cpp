@@ -34,6 +34,9 @@ public:
             for (hipEvent_t *e : {&up_done[k], &rd_det[k], &rd_reid[k]}) YDS_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         YDS_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         YDS_HIP(hipEventCreateWithFlags(&ev_feat, hipEventDisableTiming));
+        YDS_HIP(hipEventCreateWithFlags(&ev_reid_done, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k)
+            for (hipEvent_t *e : {&e_r0[k], &e_r1[k]}) YDS_HIP(hipEventCreate(e));
     }
     ~Pipeline() {
         for (int k = 0; k < 2; ++k) {
@@ -43,6 +46,9 @@ public:
             for (hipEvent_t e : {up_done[k], rd_det[k], rd_reid[k]}) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(copy_stream);
         (void)hipEventDestroy(ev_feat);
+        (void)hipEventDestroy(ev_reid_done);
+        for (int k = 0; k < 2; ++k)
+            for (hipEvent_t e : {e_r0[k], e_r1[k]}) (void)hipEventDestroy(e);
     }
 
     // ---- frames handed over as HOST memory (img_detect.py:70-71 starts from a host frame) ------------------------------
@@ -185,6 +191,15 @@ public:
         float ms01 = 0, ms12 = 0;
         YDS_HIP(hipEventElapsedTime(&ms01, e0[k], e1[k]));
         YDS_HIP(hipEventElapsedTime(&ms12, e1[k], e2[k]));
+        if (reid_in_pass[k]) {
+            // serialized schedule: the ReID pass of the PREVIOUS batch ran on this stream between the head and the tail of this
+            // pass (between e1 and e2); its own event pair takes it out of the detector's figure again, so that stage_us[1]
+            // means the same under both schedules
+            float msr = 0;
+            YDS_HIP(hipEventElapsedTime(&msr, e_r0[k], e_r1[k]));
+            ms12 -= msr;
+            reid_in_pass[k] = false;
+        }
         stage_us[0] = ms01 * 1e3f; stage_us[1] = ms12 * 1e3f;
         NmsWorkspace *nmsw = nms[k].get();
         std::vector<float> det(300 * 6);
@@ -208,15 +223,56 @@ public:
     // one ReID pass over the crops of the whole batch, asynchronous on the extractor's stream
     // `on` = the detector's stream: the pass is SERIALIZED with the detector passes (stream order) instead of sharing the CUs
     // with them from the extractor's own stream
-    void launch_reid(Dets &d, int h, int w, hipStream_t on = nullptr) {
+    // inside_pass >= 0: the pass sits between the head and the tail of the detector pass in NMS slot `inside_pass` (serialized
+    // schedule) and gets an event pair of its own (see finish_detector).
+    void launch_reid(Dets &d, int h, int w, hipStream_t on = nullptr, int inside_pass = -1) {
         d.reid_on = on ? on : reid->stream;
         if (!d.payload.empty()) {
             struct Swap { hipStream_t &s; hipStream_t keep; ~Swap() { s = keep; } } swap{reid->stream, reid->stream};
+            // Both streams' passes use the extractor's ONE set of buffers (input, activations, features, pinned crop list).  A pass
+            // on another stream than the previous one (the schedule changed, or an announced batch was abandoned) is ordered
+            // behind it explicitly; on the same stream the stream order does it.
+            if (reid_last_on && reid_last_on != d.reid_on) YDS_HIP(hipStreamWaitEvent(d.reid_on, ev_reid_done, 0));
             reid->stream = d.reid_on;
+            if (reid_last_on && reid_last_on != d.reid_on) reid->sync_before_regrow = reid_last_on;
+            if (inside_pass >= 0) YDS_HIP(hipEventRecord(e_r0[inside_pass], d.reid_on));
             reid->embed_multi_dev(d.frames, h, w, d.tlwh.data(), d.frame_of.data(), (int)d.payload.size());
+            reid->sync_before_regrow = nullptr;
+            if (inside_pass >= 0) { YDS_HIP(hipEventRecord(e_r1[inside_pass], d.reid_on)); reid_in_pass[inside_pass] = true; }
+            YDS_HIP(hipEventRecord(ev_reid_done, d.reid_on));
+            reid_last_on = d.reid_on;
             if (const int sl = slot_of(d.frames); sl >= 0) { YDS_HIP(hipEventRecord(rd_reid[sl], d.reid_on)); rd_reid_set[sl] = true; }
         }
         d.reid_in_flight = true;
+    }
+
+    // ---- stream schedule by measurement (round 5) ----------------------------------------------------------------------
+    // Which schedule is faster is a property of the box (round 4: serialized +1.2 % on one, two-stream +1.3-3.1 % on four others),
+    // so the pipeline times both on the caller's own steps, like conv_autotune times tile variants: steady-state steps (a next
+    // batch handed over, >= 256 crops) run 1 + TRIAL_STEPS serialized, then 1 + TRIAL_STEPS two-stream (the first of each group
+    // absorbs the transition), the wall time per group is taken between the returns of step(), and the faster one is kept.
+    // Results do not depend on the schedule (parity tests run both), so the trial is invisible to the caller.  One decision per
+    // entry (frames resident in HBM / uploaded inside the step): their balance differs.
+    static constexpr int TRIAL_STEPS = 3;
+    struct Trial {
+        int n = 0;                      // steady-state steps seen
+        double t0 = 0, t_serial = 0, t_two = 0;
+        int decided = 0;                // 0 = measuring, 1 = serialized, -1 = two-stream
+    };
+    // schedule of the NEXT ReID pass for entry `e` while its trial runs: serialized for the first group, two-stream for the second
+    bool trial_wants_serial(const Trial &t) const { return t.decided ? t.decided > 0 : t.n <= TRIAL_STEPS; }
+    void trial_step_done(Trial &t) {
+        using clk = std::chrono::steady_clock;
+        if (t.decided) return;
+        const double now = std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+        // step index within the trial: 0 = transition (serialized), 1..T measured, T+1 = transition (two-stream), T+2..2T+1 measured
+        if (t.n == 0 || t.n == TRIAL_STEPS + 1) t.t0 = now;
+        if (t.n == TRIAL_STEPS) t.t_serial = now - t.t0;
+        if (t.n == 2 * TRIAL_STEPS + 1) {
+            t.t_two = now - t.t0;
+            t.decided = t.t_serial <= t.t_two ? 1 : -1;
+        }
+        ++t.n;
     }
 
     void step(const uint8_t *frames_dev, const uint8_t *next_frames_dev, int next_inject_set, int h, int w, int batch, int32_t *out6,
@@ -248,9 +304,14 @@ public:
         // alternating runs on one box: 2210-2214 serialized, 2287-2295 two-stream).
         // Policy: serialize from 256 crops per batch when the frames are already in HBM and the detector runs the default arithmetic.
         // yds_pipeline_set_schedule / YDS_PIPE_SERIAL=<crops> force a threshold for either entry, -1 = never.
+        // Policy (round 5): yds_pipeline_set_schedule / YDS_PIPE_SERIAL=<crops> force a threshold (-1 = never serialize); otherwise a
+        // ReID pass of >= 256 crops takes the schedule the trial measured faster on THIS box (serialized while none has been
+        // decided: see Trial), smaller passes keep two streams.
+        const bool forced = schedule_min_crops != INT_MIN || getenv("YDS_PIPE_SERIAL");
+        Trial &trial = trials[uploaded ? 1 : 0];
         const int serial_min = schedule_min_crops != INT_MIN ? schedule_min_crops
                                : getenv("YDS_PIPE_SERIAL")  ? atoi(getenv("YDS_PIPE_SERIAL"))
-                               : (!uploaded && !net->half_mode ? 256 : -1);
+                               : (trial_wants_serial(trial) ? 256 : -1);
         int next_slot = -1;
         bool next_head_only = false;
         auto launch_next = [&](bool head_only) {                    // detector (+ NMS) of the next batch goes in flight
@@ -294,7 +355,7 @@ public:
             finish_detector(cur, slot, frames_dev, batch);
             serial = serial_min >= 0 && (int)cur.payload.size() >= std::max(serial_min, 1);
             if (serial) {
-                launch_reid(cur, h, w, net->stream);
+                launch_reid(cur, h, w, net->stream, next_head_only ? head_slot : -1);
                 copy_feats();
                 launch_next_tail();
             } else {
@@ -323,6 +384,8 @@ public:
         trk->step_batch(batch, cur.tlwh.data(), cur.first.data(), feat_cur.p, cur.payload.data(), skip.data(), out6, cap, counts);
         auto t_end = clk::now();
         stage_us[2] = us(t_begin, t_nms); stage_us[3] = us(t_nms, t_reid); stage_us[4] = us(t_reid, t_end);
+        // a steady-state step of a chip-filling ReID pass counts towards the schedule trial of its entry
+        if (!forced && next_frames_dev && D_all >= 256) trial_step_done(trial);
     }
 
     Darknet *net;
@@ -352,6 +415,11 @@ public:
     hipEvent_t e0[2] = {}, e1[2] = {}, e2[2] = {}, e_nms[2] = {};
     hipEvent_t ev_feat = nullptr;      // this batch's embeddings have been copied for the tracker
     int schedule_min_crops = INT_MIN;  // yds_pipeline_set_schedule: crops per batch from which the ReID pass is serialized (INT_MIN: policy)
+    Trial trials[2];                   // schedule trial per entry: [0] frames resident in HBM, [1] uploaded inside the step
+    hipEvent_t ev_reid_done = nullptr; // behind the last ReID pass, on the stream it ran on
+    hipStream_t reid_last_on = nullptr;
+    hipEvent_t e_r0[2] = {}, e_r1[2] = {};     // around a ReID pass enqueued inside the detector pass of NMS slot k
+    bool reid_in_pass[2] = {false, false};
     bool last_serial = false;          // schedule of the last step
     int head_slot = 0;                 // NMS slot of the pass whose head was enqueued last
     bool head_split = false, head_stale = false;
@@ -404,6 +472,14 @@ int yds_pipeline_set_schedule(yds_pipe *p, int min_crops) {
 }
 int yds_pipeline_last_schedule(yds_pipe *p) {
     return p && p->p->last_serial ? 1 : 0;
+}
+int yds_pipeline_schedule_trial(yds_pipe *p, int uploaded, int *decided, double *serialized_s, double *two_stream_s) {
+    YDS_API_BEGIN
+    const yds::Pipeline::Trial &t = p->p->trials[uploaded ? 1 : 0];
+    if (decided) *decided = t.decided;
+    if (serialized_s) *serialized_s = t.t_serial;
+    if (two_stream_s) *two_stream_s = t.t_two;
+    YDS_API_END
 }
 int yds_pipeline_stage_us(yds_pipe *p, float *us5) {
     YDS_API_BEGIN

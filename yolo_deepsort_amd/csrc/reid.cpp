@@ -237,7 +237,14 @@ void ReidNet::embed_multi_dev(const uint8_t *frames_dev, int h, int w, const flo
     crop_boxes_host(tlwh_host, D, h, w, boxes_host, frame_of);
     const int t = boxes_pin_turn ^= 1;
     if (boxes_pin_cap[t] < boxes_host.size()) {
-        if (boxes_pin[t]) { YDS_HIP(hipStreamSynchronize(stream)); (void)hipHostFree(boxes_pin[t]); boxes_pin[t] = nullptr; }
+        if (boxes_pin[t]) {
+            // the previous tenants of this list may still be read by crop kernels: on this stream, and - when the pipeline moved
+            // the pass to another stream since - on the one the earlier pass ran on
+            YDS_HIP(hipStreamSynchronize(stream));
+            if (sync_before_regrow) YDS_HIP(hipStreamSynchronize(sync_before_regrow));
+            (void)hipHostFree(boxes_pin[t]);
+            boxes_pin[t] = nullptr;
+        }
         boxes_pin_cap[t] = std::max<size_t>(boxes_host.size() * 2, 4096);
         YDS_HIP(hipHostMalloc((void **)&boxes_pin[t], boxes_pin_cap[t] * sizeof(int), hipHostMallocDefault));
     }

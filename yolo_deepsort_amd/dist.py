@@ -73,7 +73,9 @@ class Ranks:
         self.comm = None                 # yds_comm handle (RCCL) once connect() ran
         self.fallback_reason = None      # why connect() stayed on the host group although "nccl" was asked for
         self.requested = self.backend    # what the caller asked for (bench.py refuses a silent downgrade)
-        self.rows = MIN_ROWS             # rows per frame of the exchange block (grows, same value on every rank)
+        # rows per frame of the exchange block (grows, same value on every rank); YDS_EXCHANGE_ROWS: a smaller start, so that tests reach
+        # the growth path with ordinary scenes (must be the same on every rank, like every launcher-provided variable)
+        self.rows = int(os.environ.get("YDS_EXCHANGE_ROWS", MIN_ROWS))
         if self.world > 1:
             # libydsort (and with it the HIP runtime it is linked against) is mapped BEFORE torch brings its own ROCm libraries
             from . import _lib

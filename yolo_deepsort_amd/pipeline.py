@@ -60,11 +60,19 @@ class Pipeline:
 
     def set_schedule(self, min_crops=None):
         """Crops per batch from which the ReID pass is serialized with the detector passes (own stream otherwise);
-        -1 = always two streams, None = the library's policy.  Results do not depend on it."""
+        -1 = always two streams, None = the library's policy (both schedules timed on the first steady-state steps, the
+        faster one kept: schedule_trial()).  Results do not depend on it."""
         _lib.check(_lib.load().yds_pipeline_set_schedule(self._h, -2 if min_crops is None else int(min_crops)))
 
     def last_schedule(self):
         return "serialized" if _lib.load().yds_pipeline_last_schedule(self._h) else "two-stream"
+
+    def schedule_trial(self, uploaded=False):
+        """What the pipeline's schedule trial measured for an entry (frames resident in HBM / uploaded inside the step):
+        dict(decided="serialized" | "two-stream" | None while measuring, serialized_s, two_stream_s: seconds per 3 steps)."""
+        d, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+        _lib.check(_lib.load().yds_pipeline_schedule_trial(self._h, 1 if uploaded else 0, C.byref(d), C.byref(a), C.byref(b)))
+        return dict(decided={1: "serialized", -1: "two-stream"}.get(d.value), serialized_s=a.value, two_stream_s=b.value)
 
     def stage_us(self):
         us = np.zeros(5, np.float32)

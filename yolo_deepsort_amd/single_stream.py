@@ -94,6 +94,8 @@ class SingleStream:
         self.cap = MIN_DET                       # detections per frame the exchange block holds (same value on every rank)
         self.on_device = detect_dev is not None and track_dev is not None and getattr(ranks, "comm", None) is not None
         self._stage = self._all = None           # device blocks: [B][cap][512] of this rank, [world][B][cap][512] gathered
+        self._stage_cap = 0                      # rows per slot the device blocks are laid out for
+        self._held = [0] * self.B                # feature rows held per slot in the current round
         self.exchanges = 0                       # rounds exchanged (a repeated round counts once per exchange)
 
     @classmethod
@@ -143,21 +145,34 @@ class SingleStream:
         return cls(ranks, detect, track, frames_per_rank, detect_dev if device else None, track_dev if device else None)
 
     # ---- device staging -------------------------------------------------------------------------------------------------------
-    def _dev_blocks(self, cap):
-        row = EMB * 4
-        if self._stage is None or self._stage.nbytes < self.B * cap * row:
-            self._stage = _dev_block(self.B * cap * row)
-            self._all = _dev_block(self.ranks.world * self.B * cap * row)
-
-    def _stage_rows(self, items, cap):
-        """Copies the feature rows kept for this rank's frames of the round into the staging block laid out for `cap`."""
+    # One persistent block [B][cap][512] per rank: a frame's feature rows go from the extractor's buffer (complete when detect_dev
+    # returns: yds_reid_embed_dev synchronises its stream) STRAIGHT into their slot - no per-frame allocation, no device-wide
+    # synchronisation.  The block is re-laid out only when the rows per slot grow (a frame with more detections than
+    # any before, or the cap the ranks agree on in the header exchange).
+    def _relayout(self, cap, upto):
+        """Make the staging block hold `cap` rows per slot, keeping the rows already held in slots < upto."""
         from . import _lib
-        lib = _lib.load()
-        self._dev_blocks(cap)
         row = EMB * 4
-        for b, it in enumerate(items):
-            if it is not None and it[2] is not None and len(it[0]):
-                _lib.check(lib.yds_memcpy_d2d(self._stage.offset(b * cap * row), it[2].offset(0), len(it[0]) * row))
+        if self._stage is not None and self._stage_cap == cap:
+            return
+        old, old_cap = self._stage, self._stage_cap
+        self._stage = _dev_block(self.B * cap * row)
+        self._all = _dev_block(self.ranks.world * self.B * cap * row)
+        self._stage_cap = cap
+        if old is not None:
+            lib = _lib.load()
+            for s in range(upto):
+                if self._held[s]:
+                    _lib.check(lib.yds_memcpy_d2d(self._stage.offset(s * cap * row), old.offset(s * old_cap * row), self._held[s] * row))
+
+    def _hold(self, b, ptr, d):
+        """Keep the d feature rows at device pointer `ptr` (the extractor's buffer, overwritten by the next frame) in slot b."""
+        from . import _lib
+        row = EMB * 4
+        cap = max(self._stage_cap, self.cap)
+        self._relayout(cap if d <= cap else cap_for(d), upto=b)
+        _lib.check(_lib.load().yds_memcpy_d2d(self._stage.offset(b * self._stage_cap * row), ptr, d * row))
+        self._held[b] = d
 
     def run(self, frames):
         """frames: a sequence every rank can index (rank r reads frames base + r * B .. + B of every round of N * B frames).  Returns
@@ -168,6 +183,7 @@ class SingleStream:
         out = []
         for base in range(0, n, world * B):
             mine = []
+            self._held = [0] * B
             for b in range(B):
                 f = base + rank * B + b
                 if f >= n:
@@ -175,11 +191,8 @@ class SingleStream:
                 elif self.on_device:
                     got = self.detect_dev(frames[f])
                     if got is not None and got[2] is not None and len(got[0]):
-                        # the extractor's buffer is overwritten by the next frame: keep this frame's rows in a block of their own
-                        _lib.check(_lib.load().yds_device_sync())
-                        keep = _dev_block(len(got[0]) * row)
-                        _lib.check(_lib.load().yds_memcpy_d2d(keep.offset(0), got[2], len(got[0]) * row))
-                        got = (got[0], got[1], keep)
+                        self._hold(b, got[2], len(got[0]))          # the extractor's buffer is overwritten by the next frame
+                        got = (got[0], got[1], None)
                     mine.append(got)
                 else:
                     mine.append(self.detect(frames[f]))
@@ -196,7 +209,9 @@ class SingleStream:
                     break
                 self.cap = cap_for(need)                           # every rank sees the same headers and grows alike
             if self.on_device:
-                self._stage_rows(mine, self.cap)
+                # the agreed cap is the largest any rank ever needed, so it is never below this rank's own layout; one layout everywhere
+                assert self.cap >= self._stage_cap
+                self._relayout(self.cap, upto=B)
                 _lib.check(_lib.load().yds_comm_allgather_dev(self.ranks.comm, self._stage.offset(0), self.B * self.cap * row, self._all.offset(0)))
             if rank == 0:
                 for k in range(min(world * B, n - base)):
