@@ -86,6 +86,84 @@ def timed_steps(wl, ranks, sync, K, W, first, host_frames, lookahead=True, keep=
     return ranks.max_over_ranks(time.perf_counter() - t0), n_out
 
 
+class _ClipCapture:
+    """cv2.VideoCapture protocol over frames held in memory (BGR, like a decoder's output): what the demo's video file is to
+    VideoDetector.detect.  read() hands out views - the decode cost of a real file is not modelled (and not the subject)."""
+
+    def __init__(self, frames_bgr, n, fps=25.0):
+        self.frames, self.n, self.fps, self.pos = frames_bgr, n, fps, 0
+
+    def isOpened(self):
+        return True
+
+    def get(self, prop):
+        _, h, w = self.frames.shape[:3]
+        return {5: self.fps, 6: 0.0, 3: float(w), 4: float(h), 7: float(self.n), 1: float(self.pos)}[prop]
+
+    def set(self, prop, value):
+        self.pos = int(value)
+
+    def read(self):
+        if self.pos >= self.n:
+            return False, None
+        f = self.frames[self.pos % len(self.frames)]
+        self.pos += 1
+        return True, f
+
+    def release(self):
+        pass
+
+
+def video_detector_leg(config, B, seed, n_frames, device_overlay=True):
+    """The path the UNCHANGED demo takes (video_deepsort.py:13-45): VideoDetector / DeepSort through the reference's import paths
+    (the shim packages yolo3/, deep_sort/), no batch_frames keyword, a file-like source, `for image, detections, actions in
+    vd.detect(source)` - frames decoded (here: served from memory as BGR), staged, uploaded, detector + ReID + association,
+    overlay + BGR output, every result image handed to the consumer.  Returns (frames/s, per-frame host breakdown)."""
+    import tempfile
+    import numpy as np
+    from yolo3.detect.video_detect import VideoDetector              # the shim import paths of the drop-in contract
+    from yolo_deepsort_amd import cfgs, pipeline as pl
+    from yolo_deepsort_amd.workload import Workload, CONF_THRES, NMS_THRES, CLASS_MASK
+    wl = Workload(config, B, seed=seed, n_distinct=4 * B)
+    with tempfile.NamedTemporaryFile("w", suffix=".names", delete=False) as f:
+        f.write(cfgs.coco_names_text())
+    vd = VideoDetector(wl.net, f.name, thres=CONF_THRES, nms_thres=NMS_THRES, class_mask=CLASS_MASK, tracker=wl.ds, device_overlay=device_overlay)
+    os.unlink(f.name)
+    assert vd.batch_frames is None and vd.AUTO_BATCH == B
+
+    class InjectingPipeline(pl.Pipeline):                             # bench-only head-logit injection, set i for the i-th batch of the ring
+        i, sel = 0, None
+
+        def step(self, frames_dev, h, w, batch, next_frames_dev=None, select_next=None):
+            s_cur, s_next = self.i % wl.n_sets, (self.i + 1) % wl.n_sets
+            if self.sel != s_cur:
+                pl.select_injection_set(wl.net, s_cur)
+            nxt = s_next if next_frames_dev is not None else None
+            out = super().step(frames_dev, h, w, batch, next_frames_dev, select_next=nxt)
+            self.sel, self.i = nxt, self.i + 1
+            return out
+    vd._pipe = InjectingPipeline(wl.net, wl.ds, CONF_THRES, NMS_THRES, class_mask=CLASS_MASK, cap=512)
+    bgr = np.ascontiguousarray(wl.ring[..., ::-1])                    # what a decoder delivers
+    warm = 20 * B                                                     # schedule trial (16 steady-state steps) + ramp, untimed
+    cap = _ClipCapture(bgr, warm + n_frames)
+    rows = n = 0
+    t0 = None
+    for image, detections, actions in vd.detect(cap, show_fps=True):
+        n += 1
+        if n == warm:
+            t0 = time.perf_counter()
+            vd.host_us.update(wait_frames=0.0, step=0.0, overlay=0.0, frames=0)
+        elif n > warm:
+            rows += 0 if detections is None else len(detections)
+            assert image.shape == bgr.shape[1:]
+    dt = time.perf_counter() - t0
+    u = vd.host_us
+    per = {k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_frames", "step", "overlay")}
+    return (n - warm) / dt, dict(us_per_frame_main_thread=per, frames=n - warm, tracker_rows=rows, batch_frames=vd._batch_now,
+                                 output_stage="device (csrc/overlay.hip)" if vd.device_overlay else "host (numpy LabelDrawer)",
+                                 schedule=vd._pipe.last_schedule())
+
+
 def conv_roofline(variants, peak):
     """Per-variant totals -> the dominant variant's record + the all-conv record (achieved, frac, frac_of_attainable)."""
     live = [v for v in variants if v["launches"]]
@@ -260,12 +338,12 @@ def main():
 
     def settle_schedule(w, first, host_frames):
         """Set-up, like the conv autotuner's launches at plan time: the pipeline picks its stream schedule BY MEASUREMENT on the caller's
-        first steady-state steps (pipeline.cpp Trial: 4 steps serialized, 4 two-stream, the faster one kept).  These steps run here,
+        first 16 steady-state steps (pipeline.cpp Trial: groups of 4 alternating serialized / two-stream, the faster one kept).  These steps run here,
         before the W warm-up steps, so that warm-up and timed region both run the settled schedule.  Returns (steps used, record)."""
         n = 0
         if args.schedule != "policy":
             return 0, None
-        while w.pipe.schedule_trial(host_frames)["decided"] is None and n < 12:
+        while w.pipe.schedule_trial(host_frames)["decided"] is None and n < 24:
             w.step(first + n, prefetch=True, host_frames=host_frames, prefetch2=True)
             n += 1
         if n:                                                     # (leave nothing of the trial in flight across the clock start)
@@ -381,6 +459,16 @@ def main():
         del wl1
         sync()
 
+    # ---- the generator: VideoDetector.detect as the unchanged demo drives it (default arguments, shim import paths, BGR result images)
+    vd_fps, vd_rec, vd_host_fps, vd_host_rec = None, None, None, None
+    if args.latency_steps > 0 and not args.half and world == 1 and math_name != "f32":
+        try:
+            vd_fps, vd_rec = video_detector_leg(args.config, B, ranks.stream_seed(args.seed_base), 40 * B, device_overlay=True)
+            vd_host_fps, vd_host_rec = video_detector_leg(args.config, B, ranks.stream_seed(args.seed_base), 4 * B, device_overlay=False)
+        except Exception as e:                                     # noqa: BLE001 (a side leg, one rank only: no collective inside)
+            vd_rec = {"error": f"{type(e).__name__}: {e}"[:300]}
+        sync()
+
     # ---- exact-fp32 kernels (the reference's own arithmetic), short run; the network is re-planned: tensor formats depend on the
     #      conv math.  Its roofline block is measured like the default one, against the fp32-input MFMA peak.
     f32_fps, roofline_f32 = None, None
@@ -451,7 +539,7 @@ def main():
                        "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices],
                        "rank_values": rank_values,
                        "schedule_trial": None if trial is None else dict(
-                           note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds per 3 steps under either "
+                           note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds per 6 measured steps under either "
                                 "schedule on this box, per rank; `schedule` is what the timed steps then ran under",
                            per_rank=trial, with_upload=trial_up, set_up_steps=n_set),
                        **ranks.describe()},
@@ -469,6 +557,14 @@ def main():
             "value_frame_by_frame_note": "batch_frames = 1: one frame in, one result out, nothing enqueued ahead (video_detect.py:124-157); "
                                          "lookahead1 = the next frame is handed over one step early (its detector pass overlaps this frame's association)",
             "stage_us_frame_by_frame": None if fbf_stage is None else {k: round(v, 1) for k, v in fbf_stage.items()},
+            "value_video_detector": None if vd_fps is None else round(vd_fps, 2),
+            "value_video_detector_note": "VideoDetector.detect exactly as the unchanged demo calls it (video_deepsort.py:13-45: reference import paths, default "
+                                         "arguments, no batch_frames keyword) on a file-like source serving 1080p BGR frames from memory: read-ahead "
+                                         "batching by default (the reference decodes 128 frames ahead, video_detect.py:86), frames uploaded inside, "
+                                         "overlay + RGB->BGR + FPS text on the device, every BGR result image delivered to the consumer",
+            "video_detector": vd_rec,
+            "value_video_detector_host_overlay": None if vd_host_fps is None else round(vd_host_fps, 2),
+            "video_detector_host_overlay": vd_host_rec,
             "exchange": None if world == 1 else "all-gather of {count, rows[256][6]} per frame per rank after every step (%s)" % (
                 "RCCL via yds_comm_*" if ranks.comm is not None else ("gloo" + (f"; RCCL unavailable: {ranks.fallback_reason}" if ranks.fallback_reason else ""))),
             "stage_us_last_step": {k: round(v, 1) for k, v in stage.items()},

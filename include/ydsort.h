@@ -248,17 +248,36 @@ int yds_pipeline_set_next_injection(yds_pipe *, int set);
  * the choice).  min_crops >= 0: from that many crops per batch the ReID pass is enqueued on the detector's stream, between
  * the first layers of the next pass and the rest (every conv kernel has the chip to itself); -1: always two streams sharing
  * the CUs; < -1: the built-in policy (round 5: BY MEASUREMENT - for ReID passes of >= 256 crops the pipeline times both schedules on
- * the caller's first steady-state steps, 4 steps each, and keeps the faster one; one decision for yds_pipeline_step, one for
+ * the caller's first 16 steady-state steps (alternating groups of 4) and keeps the faster one; one decision for yds_pipeline_step, one for
  * yds_pipeline_step_host; two streams for smaller passes; env YDS_PIPE_SERIAL overrides; pipeline.cpp `Trial`).
  * yds_pipeline_last_schedule: 1 if the last step ran serialized, else 0.
  * yds_pipeline_schedule_trial: what the trial of an entry (uploaded = 0: yds_pipeline_step, 1: yds_pipeline_step_host) measured -
- * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds per group of 3 steps under either schedule. */
+ * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds per 6 measured steps under either schedule. */
 int yds_pipeline_set_schedule(yds_pipe *, int min_crops);
 int yds_pipeline_last_schedule(yds_pipe *);
 int yds_pipeline_schedule_trial(yds_pipe *, int uploaded, int *decided, double *serialized_s, double *two_stream_s);
 /* last step, microseconds: resize (device), detector (device: the detector pass alone - a ReID pass the serialized schedule puts
  * between its first layers and the rest is timed by its own event pair and subtracted), host wall until NMS results, ReID, association */
 int yds_pipeline_stage_us(yds_pipe *, float *us5);
+/* ---- output stage of the generator on the device ------------------------------------------------------------------
+ * yds_overlay_tracks <- LabelDrawer.draw_labels_by_trackers -> draw_rects_and_labels / draw_rects  (yolo3/utils/label_draw.py:17-60,
+ *                       171-191: box outline, filled label plate above the top-left corner, black label text) followed by the
+ *                       generator's RGB -> BGR conversion and FPS text (yolo3/detect/video_detect.py:161-186), for n_out output
+ *                       frames in ONE call.  frames_dev: uint8 RGB frames resident in HBM, h*w*3 bytes apart; output frame i is
+ *                       drawn on a channel-reversed copy of frame src_slot_host[i].  boxes_host [total][8] int32 = x1, y1, x2, y2,
+ *                       colour (c0 | c1 << 8 | c2 << 16: the class colour in the RGB image's channel order), label offset, label
+ *                       length (-1 = only_rect), 0; box_ptr_host [n_out + 1]: boxes of frame i = [box_ptr[i], box_ptr[i+1]), drawn in
+ *                       that order (a later box over an earlier one, like the sequential loop).  Text is glyph codes into font_host
+ *                       ([n_glyphs][7] row bytes of a 5 x 7 bitmap font, bit 4 = left column; `scale` device pixels per font dot -
+ *                       the stand-in for cv2's Hershey face that yolo_deepsort_amd/label_draw.py uses: pixel-identical to THAT
+ *                       host form, not to cv2's glyphs); fps_host [n_out][2] = offset, length of the frame's FPS string (0 = none),
+ *                       drawn at (3, 15), scale 2, colour (255, 0, 0) on the BGR result.  Result: out_dev (n_out frames, BGR) and,
+ *                       when out_host is given (pinned memory for full speed), a copy there; synchronous.
+ * yds_swap_rb        <- the reader's BGR -> RGB transform (video_detect.py:33-36), in place on frames already uploaded. */
+int yds_overlay_tracks(const uint8_t *frames_dev, const int32_t *src_slot_host, int n_out, int h, int w, const int32_t *boxes_host,
+                       const int32_t *box_ptr_host, const uint8_t *text_host, int n_text, const int32_t *fps_host,
+                       const uint8_t *font_host, int n_glyphs, int thickness, int scale, uint8_t *out_dev, uint8_t *out_host);
+int yds_swap_rb(uint8_t *frames_dev, size_t pixels);
 /* Per tile-variant totals of the implicit-GEMM conv kernel (yds_conv_num_variants instantiations):
  * duration in us, launch count and algorithmic flops, measured with HIP events recorded around every
  * launch on the handle's stream.  mode 1 = zero the counters and start timing, 2 = stop, 0 = read. */

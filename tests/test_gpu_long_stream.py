@@ -3,7 +3,7 @@ cfg3 / cfg5 streams - with synth.PersonScene's long occlusion windows, so that c
 (reference deep_sort/sort/track.py:146-152), persons return under new ids, tracks are re-identified after 12-28 hidden
 frames and the galleries run into nn_budget = 30 (nn_matching.py:152-155) - through the very Workload object bench.py
 times (32 frames per step, next pass prefetched; the library's own schedule policy - which times both stream schedules on these very
-steps and switches mid-stream - and each schedule forced), against rows the REFERENCE produced on the same
+steps and so switches mid-stream - and each schedule forced), against rows the REFERENCE produced on the same
 frames (oracle/gen_golden.py gen_long_stream: the body of video_detect.py:134-157 with the real Extractor).
 
 Exact: None-ness, row counts, track ids and classes of every frame; the track list (ids, states, time_since_update) after
@@ -77,14 +77,11 @@ def test_long_stream_ids_bit_exact_vs_reference(config, schedule, name):
     if name == "policy":
         # the pipeline timed both schedules on the stream's own steps (4 serialized, then two-stream: pipeline.cpp Trial) - so this run
         # also crossed from one schedule to the other in the middle of the stream, with identical rows
+        # (groups of 4 steady-state steps alternate serialized / two-stream; 16 steps decide - more than these streams have)
         n_steady = int(g["n_frames"]) // B - 1
-        if n_steady >= 8:
-            assert trial["decided"] in ("serialized", "two-stream") and trial["serialized_s"] > 0 and trial["two_stream_s"] > 0, trial
-            assert ran == trial["decided"]
-        else:
-            assert trial["decided"] is None, trial
-            if n_steady >= 5:                    # cfg2: steps 0-3 serialized, 4-7 two-stream
-                assert trial["serialized_s"] > 0 and ran == "two-stream", (trial, ran)
+        assert trial["decided"] is None, trial
+        if n_steady >= 5:                        # cfg2: steps 0-3 serialized, 4-7 two-stream
+            assert trial["serialized_s"] > 0 and ran == "two-stream", (trial, ran)
     else:
         assert ran == name and trial["decided"] is None
     deaths, births, at_budget = _events(g)

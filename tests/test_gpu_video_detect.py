@@ -160,3 +160,116 @@ def test_batched_pipeline_vs_reference_generator(case, tmp_path):
     yields = list(vd.detect(Capture(frames[..., ::-1], sc["fps"]), skip_secs=c["skip_secs"], show_fps=False))
     assert vd._pipe.i == len(groups)
     _compare(case, c, g, yields)
+
+
+def test_device_overlay_equals_host_overlay():
+    """csrc/overlay.hip (yds_overlay_tracks: box outline, label plate, label text, RGB -> BGR, FPS text for a batch of frames resident in
+    HBM) against this package's host LabelDrawer + the generator's host conversion (label_draw.py, detect.py _render_host; reference
+    yolo3/utils/label_draw.py:17-60,171-191, video_detect.py:161-186), bit for bit: boxes clipped by every border, boxes outside the
+    frame, degenerate and inverted boxes, overlapping boxes (a later one over an earlier one's label), label plates pushed down by
+    the top border, frames without rows, source slots out of order, a frame size that is not a multiple of four pixels."""
+    from yolo_deepsort_amd import _lib, cfgs
+    from yolo_deepsort_amd.detect import VideoDetector
+    from yolo_deepsort_amd.label_draw import DeviceOverlay, LabelDrawer
+    _lib.init()
+    classes = cfgs.coco_names_text().split("\n")[:-1]
+    rng = np.random.RandomState(8)
+    for (h, w, thickness) in ((1080, 1920, 2), (333, 517, 3), (120, 90, 1)):
+        drawer = LabelDrawer(classes, None, 10, thickness, (608, 608))
+        ov = DeviceOverlay(drawer)
+        n_src, n_out = 5, 7
+        frames = rng.randint(0, 256, (n_src, h, w, 3)).astype(np.uint8)
+        dev = _lib.DeviceBuffer.from_array(frames)
+        slots = [3, 0, 4, 4, 1, 2, 0]
+        holds = []
+        for i in range(n_out):
+            if i == 2:
+                holds.append(None)
+                continue
+            if i == 5:
+                holds.append([])
+                continue
+            m = 12
+            x1 = rng.randint(-60, w + 20, m)
+            y1 = rng.randint(-60, h + 20, m)
+            bw, bh = rng.randint(-10, max(w // 3, 12), m), rng.randint(-10, max(h // 2, 12), m)
+            rows = np.stack([x1, y1, x1 + bw, y1 + bh, rng.randint(1, 2000, m), rng.randint(0, 80, m)], 1).astype(np.int32)
+            rows[0, :4] = (0, 0, w - 1, h - 1)                       # the whole frame
+            rows[1, :4] = (5, 2, 40, 30)                             # plate pushed down by the top border
+            rows[2, :4] = (w - 20, h - 20, w + 30, h + 30)           # clipped by the bottom-right corner
+            rows[3, :4] = rows[1, :4] + 6                            # over the previous one's label
+            holds.append(rows)
+        fps = ["FPS: ??", "FPS: 1523", None, "FPS: 7", "", "FPS: 100", "FPS: 31"]
+        got = ov.render(dev.offset(0), slots, h, w, holds, fps)
+        vd = VideoDetector.__new__(VideoDetector)
+        vd.label_drawer, vd.tracker = drawer, object()
+        for i in range(n_out):
+            want = vd._render_host(frames[slots[i]], holds[i], fps[i])
+            assert got[i].shape == want.shape and got[i].dtype == np.uint8
+            assert np.array_equal(got[i], want), (h, w, i, int((got[i] != want).sum()))
+        # only_rect = True: no plates, no text (draw_rects, label_draw.py:17-28)
+        got = ov.render(dev.offset(0), slots[:2], h, w, holds[:2], None, only_rect=True)
+        for i in range(2):
+            img = frames[slots[i]].copy()
+            drawer.draw_labels_by_trackers(img, holds[i], only_rect=True)
+            assert np.array_equal(got[i], img[..., ::-1])
+        # the result arrays own their pinned block: they stay valid after the overlay object and later renders are gone
+        keep = got[0].copy()
+        first = got[0]
+        del got
+        more = [ov.render(dev.offset(0), slots, h, w, holds, fps) for _ in range(3)]
+        assert np.array_equal(first, keep)
+        del ov, more
+        assert np.array_equal(first, keep)
+
+
+def test_default_batching_and_device_output_stage_vs_reference_generator(tmp_path):
+    """VideoDetector as video_deepsort.py constructs it - no batch_frames keyword (VERDICT r4 'next' #4a): a capture / file source is read
+    ahead and goes through the batched pipeline, a live source (camera index, URL) keeps one frame at a time.  The capture's BGR
+    frames are uploaded as decoded and channel-swapped on the device; the yielded images come from the device output stage and equal
+    the host output stage bit for bit; rows / None-ness / actions equal what the reference's own generator yielded."""
+    from yolo_deepsort_amd import pipeline as pl
+    g = golden("video_detect")
+    case = "tracker_every_frame"
+    assert VideoDetectorAuto()._is_live(0) and VideoDetectorAuto()._is_live("rtsp://cam/1") and VideoDetectorAuto()._is_live("2")
+    assert not VideoDetectorAuto()._is_live("clip.mp4") and not VideoDetectorAuto()._is_live(iter(()))
+    images = {}
+    for device_overlay in (True, False):
+        c, sc, net, frames, inj, tracker, act, VideoDetector, cfgs = _build(case, 32)
+        vd = VideoDetector(net, _names(tmp_path, cfgs), thres=sc["thres"], nms_thres=sc["nms_thres"], skip_frames=c["skip_frames"],
+                           class_mask=c["class_mask"], tracker=tracker, action_id=act, device_overlay=device_overlay)
+        assert vd.batch_frames is None
+        index = {_key(f): t for t, f in enumerate(frames)}
+        vd._batch_now = vd.AUTO_BATCH
+        groups = [[index[_key(f)] for f, proc in grp if proc]
+                  for grp in vd._processed_batches(Capture(frames[..., ::-1], sc["fps"]), c["skip_secs"])]
+        B = vd.AUTO_BATCH
+        empty = np.zeros((0, 9), F32)
+        pl.load_injection_sets(net, [[inj[t] for t in grp] + [empty] * (B - len(grp)) for grp in groups])
+
+        class InjectingPipeline(pl.Pipeline):
+            i, sel = 0, None
+
+            def step(self, frames_dev, h, w, batch, next_frames_dev=None, select_next=None):
+                if self.sel != self.i:
+                    pl.select_injection_set(net, self.i)
+                nxt = self.i + 1 if next_frames_dev is not None else None
+                out = super().step(frames_dev, h, w, batch, next_frames_dev, select_next=nxt)
+                self.sel, self.i = nxt, self.i + 1
+                return out
+        vd._pipe = InjectingPipeline(net, tracker, vd.image_detector.thres, vd.image_detector.nms_thres, class_mask=c["class_mask"])
+        yields = list(vd.detect(Capture(frames[..., ::-1], sc["fps"]), skip_secs=c["skip_secs"], show_fps=False))
+        assert vd._pipe.i == len(groups) and vd._batch_now == 32 and vd.host_us["frames"] == len(yields)
+        _compare(case, c, g, yields)
+        images[device_overlay] = [y[0] for y in yields]
+    assert len(images[True]) == len(images[False]) > 0
+    drawn = 0
+    for a, b, f in zip(images[True], images[False], frames[int(g[f"{case}_served"][0]):]):
+        assert np.array_equal(a, b)
+        drawn += int(not np.array_equal(a, f[..., ::-1]))
+    assert drawn > 0                                                # boxes were drawn on some frames at least
+
+
+def VideoDetectorAuto():
+    from yolo_deepsort_amd.detect import VideoDetector
+    return VideoDetector

@@ -363,7 +363,7 @@ sys.path.insert(0, ref_harness.REF_ROOT)
 ref = collect()
 import yolo3.models as chk
 assert chk.__file__.startswith(ref_harness.REF_ROOT)
-extra_ok = {"VideoDetector.__init__": {"batch_frames"}, "DeepSort.__init__": {"metric"}, "Darknet.__init__": {"batch_max", "cfg_text"},
+extra_ok = {"VideoDetector.__init__": {"batch_frames", "device_overlay"}, "DeepSort.__init__": {"metric"}, "Darknet.__init__": {"batch_max", "cfg_text"},
             "Darknet.load_darknet_weights": {"blob"}}
 for name, r in ref.items():
     m = mine[name]
@@ -595,32 +595,27 @@ def test_video_generator_control_flow_vs_reference_fixture(case, batch_frames, t
 
         def spy(*a, **k):
             for grp in orig(*a, **k):
-                pipe.groups.append([index[key(f)] for f, proc in grp if proc])
+                bgr = k.get("transform", True) is False                 # a capture source is staged as the decoder's BGR (swapped on the device)
+                pipe.groups.append([index[key(f[..., ::-1] if bgr else f)] for f, proc in grp if proc])
                 yield grp
         vd._processed_batches = spy
 
         class Buf:
-            def __init__(self, arr):
-                self.arr = arr
-
-            @classmethod
-            def from_array(cls, arr):
-                return cls(arr)
-
             def offset(self, o):
                 return self
 
-            def free(self):
-                pass
-        import yolo_deepsort_amd._lib as L
-        real = L.DeviceBuffer
-        L.DeviceBuffer = Buf
+        # stand-ins for the two device hooks of the batched path: the staged group stays on the host, the output stage is the host form
+        def upload(blk, group_frames, h, w, bgr):
+            blk.update(dev=Buf(), host=[np.ascontiguousarray(f[..., ::-1]) if bgr else f for f in group_frames])
+        vd._upload_group = upload
+        vd._render_batch = lambda cur, holds, fps, bgr: [vd._render_host(cur["blk"]["host"][cur["slot_of"][i]], holds[i], None) for i in range(len(holds))]
     try:
         clip = _Clip(frames[..., ::-1], sc["fps"])
         got = list(vd.detect(clip, skip_secs=c["skip_secs"], show_fps=False))
     finally:
-        if batch_frames > 1:
-            L.DeviceBuffer = real
+        pass
+    if batch_frames > 1:
+        assert not pipe.groups and vd.host_us["frames"] == n          # the batched generator really ran (every staged group consumed)
     assert len(got) == n
     assert clip.sets == [(1, served[0])]
     for i, (result, hold, actions) in enumerate(got):

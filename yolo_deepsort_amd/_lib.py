@@ -132,6 +132,8 @@ SIGNATURES = {
     "yds_pipeline_last_schedule": (_I, [_P]),
     "yds_pipeline_schedule_trial": (_I, [_P, _I, _P, _P, _P]),
     "yds_conv_timing": (_I, [_P, _I, _P, _P, _P]),
+    "yds_overlay_tracks": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P]),
+    "yds_swap_rb": (_I, [_P, _SZ]),
 }
 
 _lib = None

@@ -249,30 +249,31 @@ public:
     // ---- stream schedule by measurement (round 5) ----------------------------------------------------------------------
     // Which schedule is faster is a property of the box (round 4: serialized +1.2 % on one, two-stream +1.3-3.1 % on four others),
     // so the pipeline times both on the caller's own steps, like conv_autotune times tile variants: steady-state steps (a next
-    // batch handed over, >= 256 crops) run 1 + TRIAL_STEPS serialized, then 1 + TRIAL_STEPS two-stream (the first of each group
-    // absorbs the transition), the wall time per group is taken between the returns of step(), and the faster one is kept.
+    // batch handed over, >= 256 crops) run in groups of 1 + TRIAL_STEPS - serialized, two-stream, serialized, two-stream; the first
+    // step of a group absorbs the transition - the wall time per group is taken between the returns of step(), and the schedule
+    // with the smaller sum is kept (16 steps in all).
     // Results do not depend on the schedule (parity tests run both), so the trial is invisible to the caller.  One decision per
     // entry (frames resident in HBM / uploaded inside the step): their balance differs.
-    static constexpr int TRIAL_STEPS = 3;
+    static constexpr int TRIAL_STEPS = 3, TRIAL_GROUPS = 4;      // groups alternate serialized / two-stream: S T S T
     struct Trial {
         int n = 0;                      // steady-state steps seen
         double t0 = 0, t_serial = 0, t_two = 0;
         int decided = 0;                // 0 = measuring, 1 = serialized, -1 = two-stream
     };
-    // schedule of the NEXT ReID pass for entry `e` while its trial runs: serialized for the first group, two-stream for the second
-    bool trial_wants_serial(const Trial &t) const { return t.decided ? t.decided > 0 : t.n <= TRIAL_STEPS; }
+    // Schedule of the NEXT ReID pass for an entry while its trial runs.  A group = one transition step + TRIAL_STEPS measured steps;
+    // the groups alternate (serialized first) and each schedule is measured twice, once earlier and once later in the run, so that
+    // the clock / temperature drift of the first second under load (the first group ran 7 % faster than steady state on one box)
+    // does not decide the comparison.
+    bool trial_wants_serial(const Trial &t) const { return t.decided ? t.decided > 0 : (t.n / (TRIAL_STEPS + 1)) % 2 == 0; }
     void trial_step_done(Trial &t) {
         using clk = std::chrono::steady_clock;
         if (t.decided) return;
         const double now = std::chrono::duration<double>(clk::now().time_since_epoch()).count();
-        // step index within the trial: 0 = transition (serialized), 1..T measured, T+1 = transition (two-stream), T+2..2T+1 measured
-        if (t.n == 0 || t.n == TRIAL_STEPS + 1) t.t0 = now;
-        if (t.n == TRIAL_STEPS) t.t_serial = now - t.t0;
-        if (t.n == 2 * TRIAL_STEPS + 1) {
-            t.t_two = now - t.t0;
-            t.decided = t.t_serial <= t.t_two ? 1 : -1;
-        }
+        const int group = t.n / (TRIAL_STEPS + 1), k = t.n % (TRIAL_STEPS + 1);
+        if (k == 0) t.t0 = now;                                   // the group's transition step has returned
+        if (k == TRIAL_STEPS) (group % 2 == 0 ? t.t_serial : t.t_two) += now - t.t0;
         ++t.n;
+        if (t.n == TRIAL_GROUPS * (TRIAL_STEPS + 1)) t.decided = t.t_serial <= t.t_two ? 1 : -1;
     }
 
     void step(const uint8_t *frames_dev, const uint8_t *next_frames_dev, int next_inject_set, int h, int w, int batch, int32_t *out6,

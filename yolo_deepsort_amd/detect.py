@@ -5,6 +5,7 @@ drawing and display stay host side and are optional (cv2 / imutils are not requi
 from __future__ import annotations
 
 import logging
+import os
 import time
 from functools import reduce
 
@@ -208,11 +209,15 @@ def _transform(frame):
 class VideoDetector:
     def __init__(self, model, class_path, thickness=2, font_path=None, font_size=10, thres=0.7, nms_thres=0.4,
                  skip_frames=-1, fourcc="mp4v", class_mask=None, win_size=None, overlap=0.15, tracker=None,
-                 action_id=None, half=False, batch_frames=1):
-        # batch_frames (not in the reference): with a tracker, read that many frames ahead and run them through the
-        # batched device pipeline (csrc/pipeline.cpp) - same results per frame, yielded in order, ~10x the frame rate of
-        # the frame-by-frame path; 1 keeps the reference's latency (one frame in, one result out)
-        self.batch_frames = max(1, int(batch_frames))
+                 action_id=None, half=False, batch_frames=None, device_overlay=True):
+        # batch_frames (not in the reference): with a tracker, read that many frames ahead and run them through the batched device
+        # pipeline (csrc/pipeline.cpp) - same results per frame, yielded in order, several times the frame rate of the frame-by-frame
+        # path.  None (default, round 5) = by source: AUTO_BATCH frames for a file / an .npy / an iterable of frames - the reference
+        # itself decodes up to 128 frames ahead of the detector for those (FileVideoStream queue, video_detect.py:86) - and 1 for a
+        # live source (a camera index, a stream URL), where reading ahead would be waiting.  1 = the reference's latency (one frame
+        # in, one result out).  device_overlay: the output stage (overlay, RGB -> BGR, FPS text) of the batched path on the device.
+        self.batch_frames = None if batch_frames is None else max(1, int(batch_frames))
+        self.device_overlay = bool(device_overlay) and not os.environ.get("YDS_HOST_OVERLAY")
         self._pipe = None
         self.thickness = thickness
         self.skip_frames = skip_frames
@@ -227,7 +232,18 @@ class VideoDetector:
         self.image_detector = ImageDetector(model, class_path, thickness=thickness, thres=thres, nms_thres=nms_thres,
                                             win_size=win_size, overlap=overlap, half=half)
 
-    def _frames(self, video_path, skip_secs=0):
+    AUTO_BATCH = 32          # frames per step of the batched path when batch_frames is left to the source (bench.py's step size)
+
+    @staticmethod
+    def _is_live(video_path):
+        """A source that cannot be read ahead of real time: a camera index (cv2.VideoCapture(0), video_detect.py:86 passes the path
+        through) or a network stream URL."""
+        if isinstance(video_path, int):
+            return True
+        return isinstance(video_path, str) and (video_path.isdigit() or "://" in video_path)
+
+    def _frames(self, video_path, skip_secs=0, transform=True):
+        """RGB frames of the source (transform=False: a capture / file source's frames as decoded, BGR)."""
         self._source_fps = None
         if hasattr(video_path, "__iter__") and not isinstance(video_path, (str, bytes)) and not hasattr(video_path, "isOpened"):
             if skip_secs:
@@ -235,7 +251,7 @@ class VideoDetector:
             for f in video_path:           # already-decoded RGB frames
                 yield f
             return
-        fvs = FileVideoStream(video_path, _transform)                # video_detect.py:86: decode thread + BGR -> RGB
+        fvs = FileVideoStream(video_path, _transform if transform else None)   # video_detect.py:86: decode thread + BGR -> RGB
         self._source_fps = fvs.fps()
         fvs.seek_secs(skip_secs)                                     # video_detect.py:99-101
         fvs.start()
@@ -266,10 +282,11 @@ class VideoDetector:
             detections = self.tracker.update(boxs.astype(np.float32), confidences, frame, class_ids)
         return detections
 
-    def _processed_batches(self, video_path, skip_secs=0):
+    def _processed_batches(self, video_path, skip_secs=0, transform=True):
         """Groups of consecutive frames holding up to batch_frames frames that pass the skip_frames gate."""
         group, n_proc, frames = [], 0, 0
-        for frame in self._frames(video_path, skip_secs):
+        bf = getattr(self, "_batch_now", None) or self.batch_frames or 1
+        for frame in self._frames(video_path, skip_secs, transform):
             if frame is None:
                 break
             proc = frames % self.skip_frames == 0
@@ -278,14 +295,14 @@ class VideoDetector:
             frames += 1
             group.append((frame, proc))
             n_proc += proc
-            if n_proc == self.batch_frames:
+            if n_proc == bf:
                 yield group
                 group, n_proc = [], 0
         if group:
             yield group
 
-    def _render(self, frame, hold_detections, show_fps):
-        """video_detect.py:161-186: overlay (on a copy: callers may hand in their own frame arrays), RGB -> BGR, FPS text."""
+    def _render_host(self, frame, hold_detections, fps_text):
+        """video_detect.py:161-186 on the host: overlay (on a copy: callers may hand in their own frame arrays), RGB -> BGR, FPS text."""
         image = frame
         if hold_detections is not None and len(hold_detections):
             image = frame.copy()
@@ -294,57 +311,161 @@ class VideoDetector:
             else:
                 self.label_drawer.draw_labels(image, hold_detections, only_rect=False)
         result = np.ascontiguousarray(image[:, :, ::-1])           # RGB -> BGR
+        if fps_text:
+            put_text(result, fps_text, (3, 15), 2, (255, 0, 0))
+        return result
+
+    def _render(self, frame, hold_detections, show_fps):
         now = time.time()
-        self._fps_acc += now - self._fps_prev
+        text = self._fps_tick(now - self._fps_prev)
         self._fps_prev = now
+        return self._render_host(frame, hold_detections, text if show_fps else None)
+
+    def _fps_tick(self, dt):
+        """The FPS counter of video_detect.py:176-182 advanced by one yielded frame that took `dt` seconds; returns the text to show."""
+        self._fps_acc += dt
         self._fps_cnt += 1
         if self._fps_acc > 1:
             self._fps_acc -= 1
             self._fps_text = "FPS: " + str(self._fps_cnt)
             self._fps_cnt = 0
-        if show_fps:
-            put_text(result, self._fps_text, (3, 15), 2, (255, 0, 0))
-        return result
+        return self._fps_text
 
-    def _detect_batched(self, video_path, show_fps=True, skip_secs=0):
-        """detect() through the batched pipeline: identical per-frame results, frames are read batch_frames ahead."""
-        from . import _lib, pipeline as pl
+    def _stage_batches(self, video_path, skip_secs, bgr, out_q, free_q, stop):
+        """Reader side of the batched path (its own thread): groups of frames -> a pinned staging block -> HBM (synchronous copy
+        on this thread, the GIL released), channel-swapped there when the source delivers BGR.  The main thread hands the
+        device blocks back through free_q once the pipeline and the overlay are done with them."""
+        try:
+            for group in self._processed_batches(video_path, skip_secs, transform=not bgr):
+                if stop.is_set():
+                    break
+                # processed frames first (the pipeline wants them contiguous), the others behind them
+                order = [i for i, (_, proc) in enumerate(group) if proc] + [i for i, (_, proc) in enumerate(group) if not proc]
+                n_proc = sum(1 for _, proc in group if proc)
+                h, w = group[0][0].shape[:2]
+                if any(f.shape != (h, w, 3) or f.dtype != np.uint8 for f, _ in group):
+                    raise ValueError("VideoDetector: frames of one video must share one uint8 [h, w, 3] shape")
+                blk = free_q.get()
+                if blk is None or stop.is_set():
+                    return
+                slot_of = [0] * len(group)
+                for slot, i in enumerate(order):
+                    slot_of[i] = slot
+                self._upload_group(blk, [group[i][0] for i in order], h, w, bgr)
+                out_q.put(dict(blk=blk, flags=[proc for _, proc in group], slot_of=slot_of, n_proc=n_proc, h=h, w=w))
+            out_q.put(None)
+        except BaseException as e:                                             # noqa: BLE001 - re-raised on the consumer's thread
+            out_q.put(e)
+
+    @staticmethod
+    def _upload_group(blk, frames, h, w, bgr):
+        """The device side of the reader thread: `frames` (slot order) -> the block's pinned staging array -> its HBM buffer; a BGR
+        source is channel-swapped there (yds_swap_rb).  blk["dev"] / blk["pin"] are (re)allocated when the group outgrows them."""
+        from . import _lib
+        lib = _lib.load()
+        nbytes = len(frames) * h * w * 3
+        if blk["dev"] is None or blk["dev"].nbytes < nbytes:
+            blk["dev"] = _lib.DeviceBuffer(nbytes)
+            blk["pin"] = _lib.PinnedArray((nbytes,), np.uint8)
+        stage = blk["pin"].array[:nbytes].reshape(len(frames), h, w, 3)
+        for slot, f in enumerate(frames):
+            np.copyto(stage[slot], f)
+        _lib.check(lib.yds_memcpy_h2d(blk["dev"].ptr, _lib.ptr(stage), nbytes))
+        if bgr:
+            _lib.check(lib.yds_swap_rb(blk["dev"].ptr, len(frames) * h * w))
+
+    def _render_batch(self, cur, holds, fps_texts, bgr):
+        """Output stage of one staged batch: a list of BGR frames in group order.  Device form: csrc/overlay.hip over the frames in
+        HBM; host form (device_overlay=False / YDS_HOST_OVERLAY: A/B runs and tests): label_draw.py on the staged copy."""
+        h, w, n = cur["h"], cur["w"], len(holds)
+        if self.device_overlay:
+            from .label_draw import DeviceOverlay
+            if getattr(self, "_overlay", None) is None:
+                self._overlay = DeviceOverlay(self.label_drawer)
+            return self._overlay.render(cur["blk"]["dev"].offset(0), cur["slot_of"], h, w, holds, fps_texts)
+        stage = cur["blk"]["pin"].array[:n * h * w * 3].reshape(n, h, w, 3)
+        if bgr:
+            stage = stage[..., ::-1]
+        return [self._render_host(np.ascontiguousarray(stage[cur["slot_of"][i]]), holds[i], fps_texts[i] if fps_texts else None) for i in range(n)]
+
+    def _detect_batched(self, video_path, show_fps=True, skip_secs=0, batch_frames=None):
+        """detect() through the batched pipeline: identical per-frame results, frames are read batch_frames ahead (the reference itself
+        decodes up to 128 frames ahead, video_detect.py:86).  Round 5: frames go reader thread -> pinned staging -> HBM once; the
+        pipeline and the OUTPUT STAGE (overlay, RGB -> BGR, FPS text: csrc/overlay.hip) both read them there, the rendered batch comes
+        back in one D2H copy.  A capture / file source is uploaded as the BGR the decoder delivers and channel-swapped on the device
+        (the reference converts on the host, video_detect.py:33-36)."""
+        import queue
+        import threading
         det = self.image_detector
+        bf = batch_frames or self.batch_frames or 1
         if self._pipe is None:
-            if det.model.batch_max < self.batch_frames:
-                det.model.set_batch_max(self.batch_frames)
+            from . import pipeline as pl
+            if det.model.batch_max < bf:
+                det.model.set_batch_max(bf)
             self._pipe = pl.Pipeline(det.model, self.tracker, det.thres, det.nms_thres, class_mask=self.class_mask)
+        self._batch_now = bf
+        iterable = hasattr(video_path, "__iter__") and not isinstance(video_path, (str, bytes)) and not hasattr(video_path, "isOpened")
+        out_q, free_q, stop = queue.Queue(maxsize=2), queue.Queue(), threading.Event()
+        for _ in range(5):                       # main holds two (this batch, the next), two wait in out_q, one is being filled
+            free_q.put(dict(dev=None, pin=None))
+        th = threading.Thread(target=self._stage_batches, args=(video_path, skip_secs, not iterable, out_q, free_q, stop), daemon=True)
+        th.start()
+
+        def take():
+            item = out_q.get()
+            if isinstance(item, BaseException):
+                raise item
+            return item
         hold_detections, actions = None, []
-
-        def upload(group):
-            fr = [f for f, proc in group if proc]
-            return (_lib.DeviceBuffer.from_array(np.stack(fr, 0)), fr[0].shape[0], fr[0].shape[1], len(fr)) if fr else None
-
-        groups = self._processed_batches(video_path, skip_secs)
-        cur = next(groups, None)
-        cur_dev = upload(cur) if cur is not None else None
-        while cur is not None:
-            nxt = next(groups, None)
-            nxt_dev = upload(nxt) if nxt is not None else None
-            outs = []
-            if cur_dev is not None:
-                buf, h, w, n = cur_dev
-                ahead = nxt_dev[0].offset(0) if nxt_dev is not None and nxt_dev[1:] == (h, w, n) else None
-                outs = self._pipe.step(buf.offset(0), h, w, n, ahead)
-            k = 0
-            for frame, proc in cur:
-                if proc:
-                    o = outs[k]
-                    k += 1
-                    hold_detections = None if o is None else (o if len(o) else [])
-                    if hold_detections is not None:        # video_detect.py:137-154; a detector-None frame leaves `actions` as it was
-                        actions = self.action_id.update(hold_detections) if self.action_id is not None else []
-                else:
-                    actions = []                           # :158-159
-                yield self._render(frame, hold_detections, show_fps), hold_detections, actions
-            if cur_dev is not None:
-                cur_dev[0].free()
-            cur, cur_dev = nxt, nxt_dev
+        self.host_us = dict(wait_frames=0.0, step=0.0, overlay=0.0, frames=0)
+        t_prev = time.time()
+        try:
+            t0 = time.perf_counter()
+            cur = take()
+            self.host_us["wait_frames"] += (time.perf_counter() - t0) * 1e6
+            while cur is not None:
+                t0 = time.perf_counter()
+                nxt = take()
+                t1 = time.perf_counter()
+                outs = []
+                h, w, n = cur["h"], cur["w"], cur["n_proc"]
+                if n:
+                    ahead = nxt["blk"]["dev"].offset(0) if nxt is not None and (nxt["h"], nxt["w"], nxt["n_proc"]) == (h, w, n) else None
+                    outs = self._pipe.step(cur["blk"]["dev"].offset(0), h, w, n, ahead)
+                t2 = time.perf_counter()
+                holds, acts, k = [], [], 0
+                for proc in cur["flags"]:
+                    if proc:
+                        o = outs[k]
+                        k += 1
+                        hold_detections = None if o is None else (o if len(o) else [])
+                        if hold_detections is not None:        # video_detect.py:137-154; a detector-None frame leaves `actions` as it was
+                            actions = self.action_id.update(hold_detections) if self.action_id is not None else []
+                    else:
+                        actions = []                           # :158-159
+                    holds.append(hold_detections)
+                    acts.append(actions)
+                now = time.time()
+                dt = (now - t_prev) / len(holds)
+                t_prev = now
+                fps = [self._fps_tick(dt) for _ in holds]
+                results = self._render_batch(cur, holds, fps if show_fps else None, not iterable)
+                t3 = time.perf_counter()
+                free_q.put(cur["blk"])
+                u = self.host_us
+                u["wait_frames"] += (t1 - t0) * 1e6; u["step"] += (t2 - t1) * 1e6; u["overlay"] += (t3 - t2) * 1e6; u["frames"] += len(holds)
+                for i in range(len(holds)):
+                    yield results[i], holds[i], acts[i]
+                cur = nxt
+        finally:
+            stop.set()
+            free_q.put(None)
+            try:
+                while True:
+                    out_q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=5)
 
     def detect(self, video_path, output_path=None, skip_secs=0, real_show=False, show_fps=True):
         """Generator of (bgr_image, hold_detections, actions) like video_detect.py:78-199.  output_path: every result is
@@ -387,9 +508,10 @@ class VideoDetector:
 
     def _detect_impl(self, video_path, show_fps=True, skip_secs=0):
         # (the tracker-side NMS option reorders detections on the host, so it keeps the frame-by-frame path)
-        if (self.batch_frames > 1 and self.tracker is not None and self.image_detector.win_size is None
+        bf = self.batch_frames if self.batch_frames is not None else (1 if self._is_live(video_path) else self.AUTO_BATCH)
+        if (bf > 1 and self.tracker is not None and self.image_detector.win_size is None
                 and getattr(self.tracker, "nms_max_overlap", 1) == 1):
-            yield from self._detect_batched(video_path, show_fps, skip_secs)
+            yield from self._detect_batched(video_path, show_fps, skip_secs, bf)
             return
         hold_detections, actions, frames = None, [], 0
         for frame in self._frames(video_path, skip_secs):

@@ -138,3 +138,120 @@ class LabelDrawer:
                 labels.append(key + ":" + name)
             draw_rects_and_labels(img, detections, self.colors, labels, self.thickness, img.shape[0] / 1000.)
         return img, None, None
+
+
+# ---- device form of draw_labels_by_trackers + RGB -> BGR + FPS text (csrc/overlay.hip, yds_overlay_tracks) ---------------------------
+_GLYPH_ORDER = sorted(_FONT)
+_GLYPH_CODE = {ch: i for i, ch in enumerate(_GLYPH_ORDER)}
+
+
+def font_table():
+    """uint8 [n_glyphs, 7]: the row bytes of the 5 x 7 glyphs in code order (bit 4 = left column)."""
+    return np.array([[int(_FONT[ch][2 * r:2 * r + 2], 16) for r in range(7)] for ch in _GLYPH_ORDER], dtype=np.uint8)
+
+
+def encode_text(text):
+    """Glyph codes of `text` as put_text draws it (lower-cased, unknown characters as '_')."""
+    return np.array([_GLYPH_CODE.get(ch.lower(), _GLYPH_CODE["_"]) for ch in text], dtype=np.uint8)
+
+
+class _PinnedBlock:
+    """A pinned host block (yds_host_alloc) whose lifetime follows the numpy arrays made of it: np.asarray(block) and every
+    view of that keep the block alive; it is handed back to the runtime when the last one is gone."""
+
+    def __init__(self, nbytes):
+        from . import _lib
+        self.nbytes = int(nbytes)
+        self.ptr = _lib.check_ptr(_lib.load().yds_host_alloc(self.nbytes))
+        self.__array_interface__ = dict(shape=(self.nbytes,), typestr="|u1", data=(self.ptr, False), version=3)
+
+    def __del__(self):
+        try:
+            from . import _lib
+            if self.ptr:
+                _lib.load().yds_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+class DeviceOverlay:
+    """LabelDrawer.draw_labels_by_trackers for a whole batch of frames that are resident in HBM, with the generator's RGB -> BGR
+    conversion and FPS text (video_detect.py:161-186) in the same pass.  Pixel-identical to this module's host functions."""
+
+    def __init__(self, drawer):
+        self.drawer = drawer
+        self.font = font_table()
+        self._labels = {}                # (track id, class) -> glyph codes
+        self._out_dev = None
+        self._pool = []                  # pinned result blocks; one is reused once no array handed out still refers to it
+
+    def _pinned(self, nbytes):
+        import sys
+        for blk in self._pool:
+            if blk.nbytes >= nbytes and sys.getrefcount(blk) <= 3:          # the list, the loop variable, getrefcount's argument
+                return blk
+        if len(self._pool) >= 4:                                            # keep the pool small; blocks still referenced live on with their arrays
+            self._pool = [b for b in self._pool if sys.getrefcount(b) > 3][-3:]
+        blk = _PinnedBlock(nbytes)
+        self._pool.append(blk)
+        return blk
+
+    def _label(self, tid, cls):
+        key = (tid, cls)
+        codes = self._labels.get(key)
+        if codes is None:
+            d = self.drawer
+            name = d.id2label[str(tid)] if d.id2label is not None and str(tid) in d.id2label else d.classes[cls]
+            codes = self._labels[key] = encode_text(str(tid) + ":" + name)
+            if len(self._labels) > 100000:
+                self._labels.clear()
+        return codes
+
+    def render(self, frames_dev, src_slots, h, w, holds, fps_texts=None, only_rect=False):
+        """frames_dev: device pointer of uint8 RGB frames, h*w*3 bytes apart; output i shows frame src_slots[i] with the tracker
+        rows holds[i] (int32 [m,6], or None / empty: nothing drawn).  Returns a list of BGR uint8 [h,w,3] arrays (views of one
+        pinned block that stays alive as long as any of them does)."""
+        from . import _lib
+        n = len(holds)
+        if n == 0:
+            return []
+        d = self.drawer
+        colors, ncol = d.colors, len(d.colors)
+        boxes, ptr, texts, toff = [], [0], [], 0
+        for hold in holds:
+            if hold is not None and len(hold):
+                for r in np.asarray(hold, dtype=np.int64).reshape(-1, 6).tolist():
+                    c = colors[r[5] % ncol]
+                    if only_rect:
+                        off, ln = 0, -1
+                    else:
+                        codes = self._label(r[4], r[5])
+                        off, ln = toff, len(codes)
+                        texts.append(codes)
+                        toff += ln
+                    boxes.append((r[0], r[1], r[2], r[3], c[0] | (c[1] << 8) | (c[2] << 16), off, ln, 0))
+            ptr.append(len(boxes))
+        fps = np.zeros((n, 2), np.int32)
+        if fps_texts is not None:
+            for i, t in enumerate(fps_texts):
+                if t:
+                    codes = encode_text(t)
+                    fps[i] = (toff, len(codes))
+                    texts.append(codes)
+                    toff += len(codes)
+        text = np.ascontiguousarray(np.concatenate(texts) if texts else np.zeros(1, np.uint8))
+        boxes_a = np.ascontiguousarray(np.array(boxes, dtype=np.int32).reshape(-1, 8)) if boxes else np.zeros((1, 8), np.int32)
+        ptr_a = np.ascontiguousarray(ptr, dtype=np.int32)
+        slots = np.ascontiguousarray(src_slots, dtype=np.int32)
+        nbytes = n * h * w * 3
+        if self._out_dev is None or self._out_dev.nbytes < nbytes:
+            self._out_dev = _lib.DeviceBuffer(nbytes)
+        blk = self._pinned(nbytes)
+        scale = max(1, int(round(2 * (h / 1000.))))                      # draw_rects_and_labels' font_size = img.shape[0] / 1000.
+        _lib.check(_lib.load().yds_overlay_tracks(frames_dev, _lib.ptr(slots), n, h, w, _lib.ptr(boxes_a), _lib.ptr(ptr_a), _lib.ptr(text), toff,
+                                                  _lib.ptr(fps), _lib.ptr(self.font), len(self.font), int(d.thickness), scale,
+                                                  self._out_dev.ptr, blk.ptr))
+        out = np.asarray(blk)[:nbytes].reshape(n, h, w, 3)
+        del blk
+        return [out[i] for i in range(n)]
