@@ -16,6 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench_$cfg$sfx -
 cd $R
 python tools/rocprof_agg.py $out/bench_${cfg}${sfx}_kernel_stats.csv > $out/${cfg}${sfx}_conv_by_tile.txt
 python tools/rocprof_by_grid.py $out/bench_${cfg}${sfx}_kernel_trace.csv > $out/${cfg}${sfx}_conv_by_grid.txt
+python tools/timeline_overlap.py $out/bench_${cfg}${sfx}_kernel_trace.csv 0.4 > $out/${cfg}${sfx}_timeline.txt
 ls $out
 # HBM traffic of the conv kernels: PMC passes of their own (kernel trace only), FETCH_SIZE and WRITE_SIZE separately
 if [ "${PMC:-0}" = "1" ]; then

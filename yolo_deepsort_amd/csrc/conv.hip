@@ -76,6 +76,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
     // running decomposition of this thread's k = kt*32 + cq*4 into (kh, kw, c)
     int kk = cq * 4, kh = 0, kw = 0, kc = kk;
     while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
+    // K walk (round 5).  The weights' K order is (kh, kw, c) and a dot product does not care in which order its K steps run.  Walking
+    // tap-outermost makes a workgroup stream its whole halo'd input tile - (BM + 2 W + 2) pixels x Cin x 4 B, 144 KB at 76 x 76 x 128 -
+    // once per filter row: 64 resident workgroups per XCD hold 9 MB of live input against 4 MB of L2, the taps re-fetch what the
+    // previous tap evicted (PMC: 1079 MB per launch against 333 MB algorithmic on the 76 x 76 128 -> 256 layer, 3.2x).  When the
+    // channel count is a multiple of the K step the walk is CHANNEL-CHUNK outermost, tap innermost instead: the nine taps of one
+    // BK-channel slice touch (BM + 2 W + 2) x BK x 4 B = 36 KB per workgroup, 2.3 MB per XCD - they hit in L2, the tensor comes from
+    // HBM once.  Same products, another fp32 summation order (fixed per layer: results stay run-to-run identical).
+    const bool chunk_outer = p.ksize > 1 && p.Cin % BK == 0;
 
     // Global -> register staging, THREE tiles deep (round 4): while tile t feeds the MFMAs out of LDS, tile t+1 sits landed in
     // one register set and goes to LDS during this step, tile t+2 is in flight in the second and the loads of tile t+3 are
@@ -119,6 +127,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(ConvKernelArgs p) {
         }
     };
     auto advance_k = [&]() {
+        if (chunk_outer) {                            // next tap of this channel slice; after the last tap, the next slice
+            if (++kw == p.ksize) { kw = 0; if (++kh == p.ksize) { kh = 0; kc += BK; } }
+            kk = (kh * p.ksize + kw) * p.Cin + kc;
+            return;
+        }
         kk += BK;
         kc += BK;
         while (kc >= p.Cin) { kc -= p.Cin; if (++kw == p.ksize) { kw = 0; ++kh; } }
