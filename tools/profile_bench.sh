@@ -16,7 +16,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out -o bench_$cfg$sfx -
 cd $R
 python tools/rocprof_agg.py $out/bench_${cfg}${sfx}_kernel_stats.csv > $out/${cfg}${sfx}_conv_by_tile.txt
 python tools/rocprof_by_grid.py $out/bench_${cfg}${sfx}_kernel_trace.csv > $out/${cfg}${sfx}_conv_by_grid.txt
-python tools/timeline_overlap.py $out/bench_${cfg}${sfx}_kernel_trace.csv 0.4 > $out/${cfg}${sfx}_timeline.txt
+# what runs beside what (is the association on the critical path?): a trace of timed steps only - no roofline leg, no side legs
+if [ "${TIMELINE:-0}" = "1" ]; then
+  cd /tmp
+  rocprofv3 --kernel-trace --output-format csv -d $out -o tl_$cfg$sfx -- python $R/bench.py $common --steps 60 --warmup 3 --no-roofline > $out/bench_${cfg}${sfx}_timeline_run.json 2>$out/err_tl.log
+  cd $R
+  python tools/timeline_overlap.py $out/tl_${cfg}${sfx}_kernel_trace.csv 0.5 0.95 > $out/${cfg}${sfx}_timeline.txt
+  cat $out/${cfg}${sfx}_timeline.txt
+fi
 ls $out
 # HBM traffic of the conv kernels: PMC passes of their own (kernel trace only), FETCH_SIZE and WRITE_SIZE separately
 if [ "${PMC:-0}" = "1" ]; then
