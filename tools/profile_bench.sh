@@ -21,7 +21,7 @@ if [ "${TIMELINE:-0}" = "1" ]; then
   cd /tmp
   rocprofv3 --kernel-trace --output-format csv -d $out -o tl_$cfg$sfx -- python $R/bench.py $common --steps 60 --warmup 3 --no-roofline > $out/bench_${cfg}${sfx}_timeline_run.json 2>$out/err_tl.log
   cd $R
-  python tools/timeline_overlap.py $out/tl_${cfg}${sfx}_kernel_trace.csv 0.5 0.95 > $out/${cfg}${sfx}_timeline.txt
+  python tools/timeline_overlap.py $out/tl_${cfg}${sfx}_kernel_trace.csv 0.35 0.98 > $out/${cfg}${sfx}_timeline.txt
   cat $out/${cfg}${sfx}_timeline.txt
 fi
 ls $out

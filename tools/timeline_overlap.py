@@ -9,8 +9,8 @@ the wall time of the steady part of the run is split into
 and the tracker kernels' own busy time is reported with the share of it that runs UNDER convolution kernels (hidden).
 
     python tools/timeline_overlap.py <kernel_trace.csv> [from = 0.3] [to = 1.0]  > profiles/rNN_<cfg>_timeline.txt
-(fractions of the traced time span: tools/profile_bench.sh TIMELINE=1 traces `bench.py --no-roofline --no-extras --steps 60`, whose timed
-steps are the last ~2/3 of the span, and cuts the window well inside them).  Under the profiler every dispatch carries tracing overhead
+(fractions of the span between the first and the last tracker kernel, i.e. of the pipeline steps of the run: tools/profile_bench.sh
+TIMELINE=1 traces `bench.py --no-roofline --no-extras --steps 60` and cuts the window inside the timed steps).  Under the profiler every dispatch carries tracing overhead
 (the run is ~15 % slower than untraced), which shows up as "no kernel at all"; the question the table answers is what runs BESIDE what."""
 import csv
 import sys
@@ -50,13 +50,16 @@ def main(path, skip=0.3, upto=1.0):
     with open(path) as f:
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Kernel_Name") or r.get("Name")))
-    t_lo, t_hi = min(r[0] for r in rows), max(r[1] for r in rows)
-    cut = t_lo + int((t_hi - t_lo) * skip)                 # drop set-up, autotune and the schedule trial
+    is_trk = lambda n: any(k in n for k in ("trk_", "lsap", "kf_", "kalman", "cost_kernel", "normalize_rows", "gallery"))
+    # the reference span = first .. last tracker kernel: the pipeline steps of the run (plan-time autotune launches and the host-side
+    # set-up between them and the first step carry no tracker kernel); `skip` drops the schedule trial and warm-up steps at its front
+    steps = [r for r in rows if is_trk(r[2])]
+    t_lo, t_hi = min(r[0] for r in steps), max(r[1] for r in steps)
+    cut = t_lo + int((t_hi - t_lo) * skip)
     end = t_lo + int((t_hi - t_lo) * upto)
     rows = [r for r in rows if r[0] >= cut and r[1] <= end]
     t_lo, t_hi = min(r[0] for r in rows), max(r[1] for r in rows)
     is_conv = lambda n: "conv" in n
-    is_trk = lambda n: any(k in n for k in ("trk_", "lsap", "kf_", "kalman", "cost_kernel", "normalize_rows", "gallery"))
     conv = union([(a, b) for a, b, n in rows if is_conv(n)])
     trk = union([(a, b) for a, b, n in rows if is_trk(n)])
     other = union([(a, b) for a, b, n in rows if not is_conv(n) and not is_trk(n)])
@@ -66,7 +69,7 @@ def main(path, skip=0.3, upto=1.0):
     trk_only = length(trk) - trk_under
     oth_only = length(other) - length(intersect(other, union(conv + trk)))
     n_trk = sum(1 for _, _, n in rows if is_trk(n))
-    print(f"trace window            {wall / 1e6:10.2f} ms  ({len(rows)} kernel launches, {skip:.0%} .. {upto:.0%} of the traced span)")
+    print(f"trace window            {wall / 1e6:10.2f} ms  ({len(rows)} kernel launches, {skip:.0%} .. {upto:.0%} of the span of pipeline steps)")
     print(f"conv kernels active     {length(conv) / 1e6:10.2f} ms  {length(conv) / wall:7.1%} of the wall time")
     print(f"tracker kernels active  {length(trk) / 1e6:10.2f} ms  {length(trk) / wall:7.1%}   ({n_trk} launches)")
     print(f"  under conv kernels    {trk_under / 1e6:10.2f} ms  {trk_under / max(length(trk), 1):7.1%} of the tracker's busy time is hidden")
