@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void overlay_copy_kernel(const uint8_t *frames
     const int i = blockIdx.y;
     const uint8_t *src = frames + (size_t)src_slot[i] * frame_bytes;
     uint8_t *dst = out + (size_t)i * frame_bytes;
-    if (aligned) {
+    if (aligned) {                                   // (the launcher sets it only when frame_bytes is a multiple of 12)
         const size_t quads = frame_bytes / 12;
         const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src);
         uint32_t *d4 = reinterpret_cast<uint32_t *>(dst);
@@ -34,9 +34,6 @@ __global__ __launch_bounds__(256) void overlay_copy_kernel(const uint8_t *frames
             const uint32_t o1 = (w1 & 0xff) | ((w0 >> 24) << 8) | ((w2 & 0xff) << 16) | (w1 & 0xff000000);                    // d1 d0 e2 e1
             const uint32_t o2 = ((w1 >> 16) & 0xff) | ((w2 >> 24) << 8) | (w2 & 0xff0000) | ((w2 & 0xff00) << 16);            // e0 f2 f1 f0
             d4[3 * q] = o0; d4[3 * q + 1] = o1; d4[3 * q + 2] = o2;
-        }
-        for (size_t b = quads * 12 + (blockIdx.x * (size_t)blockDim.x + threadIdx.x) * 3; b + 2 < frame_bytes; b += (size_t)gridDim.x * blockDim.x * 3) {
-            dst[b] = src[b + 2]; dst[b + 1] = src[b + 1]; dst[b + 2] = src[b];
         }
     } else {
         const size_t pixels = frame_bytes / 3;
@@ -122,14 +119,25 @@ __global__ __launch_bounds__(256) void overlay_draw_kernel(uint8_t *out, size_t 
         put_text(img, H, W, a.text + a.fps[2 * i], a.fps[2 * i + 1], a.font, 3, 15, 2, 255, 0, 0);
 }
 
+// Two host threads use this file concurrently in the generator (detect.py): the reader thread swaps the channels of the batch it has
+// just uploaded, the consumer thread renders the previous one.  Each gets its own stream and its own scratch, created once
+// (function-local statics: initialisation is thread safe) - a swap never queues behind a 200 MB result copy.
 struct OverlayState {
     hipStream_t stream = nullptr;
     DevBuf<int> boxes, box_ptr, fps, slots;
     DevBuf<uint8_t> text, font;
+    OverlayState() { YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
 };
 OverlayState &state() {
     static OverlayState s;
-    if (!s.stream) YDS_HIP(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    return s;
+}
+struct SwapState {
+    hipStream_t stream = nullptr;
+    SwapState() { YDS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
+};
+SwapState &swap_state() {
+    static SwapState s;
     return s;
 }
 
@@ -141,7 +149,7 @@ extern "C" {
 int yds_swap_rb(uint8_t *frames_dev, size_t pixels) {
     YDS_API_BEGIN
     if (!frames_dev) yds::fail("swap_rb: NULL frames");
-    yds::OverlayState &s = yds::state();
+    yds::SwapState &s = yds::swap_state();
     if (pixels) {
         const unsigned blocks = (unsigned)std::min<size_t>((pixels + 255) / 256, 65535u * 4);
         yds::swap_rb_kernel<<<blocks, 256, 0, s.stream>>>(frames_dev, pixels);
