@@ -624,3 +624,74 @@ def test_video_generator_control_flow_vs_reference_fixture(case, batch_frames, t
         if ref is not None:
             assert np.array_equal(np.asarray(hold).reshape(-1, 6), np.asarray(ref).reshape(-1, 6)), (case, i)
         assert json.loads(json.dumps(actions)) == json.loads(str(g[f"{case}_f{i}_actions"])), (case, i, actions, str(g[f"{case}_f{i}_actions"]))
+
+
+def test_batched_generator_stops_cleanly_when_the_consumer_leaves(tmp_path):
+    """The batched path of VideoDetector.detect runs a reader and an engine thread next to the generator (detect.py): a consumer that
+    breaks out after a few frames (video_deepsort.py's `q` key, an exception in the loop body) must not leave them running or blocked,
+    and an exception on either thread must surface in the consumer."""
+    import threading
+    import time
+    from yolo_deepsort_amd import detect as D
+
+    class Model:
+        img_size, batch_max = (64, 64), 64
+
+        def eval(self):
+            return self
+
+        def parameters(self):
+            yield type("P", (), {"device": "cpu"})()
+
+    class Tracker:
+        nms_max_overlap = 1.0
+
+    class Buf:
+        def offset(self, o):
+            return self
+
+    class Pipe:
+        def __init__(self, fail_at=None):
+            self.n, self.fail_at = 0, fail_at
+
+        def step(self, buf, h, w, n, ahead=None, select_next=None):
+            self.n += 1
+            if self.fail_at == self.n:
+                raise RuntimeError("device fell over")
+            time.sleep(0.005)
+            return [np.zeros((1, 6), np.int32) for _ in range(n)]
+
+    names = tmp_path / "coco.names"
+    names.write_text(cfgs.coco_names_text())
+
+    def make(pipe):
+        vd = D.VideoDetector(Model(), str(names), tracker=Tracker(), batch_frames=4)
+        vd._pipe = pipe
+        vd._upload_group = lambda blk, fr, h, w, bgr: blk.update(dev=Buf(), host=list(fr))
+        vd._render_batch = lambda cur, holds, fps, bgr: [vd._render_host(cur["blk"]["host"][cur["slot_of"][i]], holds[i], None) for i in range(len(holds))]
+        return vd
+    before = threading.active_count()
+    gen = make(Pipe()).detect((np.zeros((48, 64, 3), np.uint8) for _ in range(10000)), show_fps=False)
+    for i, _ in enumerate(gen):
+        if i == 5:
+            break
+    gen.close()
+    deadline = time.time() + 3
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() == before
+    # a failing step: raised where the consumer iterates
+    with pytest.raises(RuntimeError, match="device fell over"):
+        for _ in make(Pipe(fail_at=3)).detect((np.zeros((48, 64, 3), np.uint8) for _ in range(100)), show_fps=False):
+            pass
+    # a failing source (frames of two shapes): raised in the consumer too
+    def bad():
+        for i in range(20):
+            yield np.zeros((48, 64 if i < 6 else 65, 3), np.uint8)
+    with pytest.raises(ValueError, match="share one"):
+        for _ in make(Pipe()).detect(bad(), show_fps=False):
+            pass
+    deadline = time.time() + 3
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() == before
