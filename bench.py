@@ -152,14 +152,15 @@ def video_detector_leg(config, B, seed, n_frames, device_overlay=True):
         n += 1
         if n == warm:
             t0 = time.perf_counter()
-            vd.host_us.update(wait_frames=0.0, step=0.0, overlay=0.0, frames=0)
+            vd.host_us.update({k: 0.0 for k in vd.host_us}, frames=0)
         elif n > warm:
             rows += 0 if detections is None else len(detections)
             assert image.shape == bgr.shape[1:]
     dt = time.perf_counter() - t0
     u = vd.host_us
-    per = {k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_frames", "step", "overlay")}
-    return (n - warm) / dt, dict(us_per_frame_main_thread=per, frames=n - warm, tracker_rows=rows, batch_frames=vd._batch_now,
+    per = {"engine: " + k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_frames", "step", "wait_consumer")}
+    per.update({"consumer: " + k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_engine", "overlay")})
+    return (n - warm) / dt, dict(us_per_frame_by_thread=per, frames=n - warm, tracker_rows=rows, batch_frames=vd._batch_now,
                                  output_stage="device (csrc/overlay.hip)" if vd.device_overlay else "host (numpy LabelDrawer)",
                                  schedule=vd._pipe.last_schedule())
 

@@ -420,7 +420,7 @@ class VideoDetector:
         out_q, done_q, free_q, stop = queue.Queue(maxsize=1), queue.Queue(maxsize=1), queue.Queue(), threading.Event()
         for _ in range(6):           # one being filled, one in out_q, two with the engine (this batch, the next), one in done_q, one being rendered
             free_q.put(dict(dev=None, pin=None))
-        self.host_us = dict(wait_frames=0.0, step=0.0, overlay=0.0, wait_engine=0.0, frames=0)
+        self.host_us = dict(wait_frames=0.0, step=0.0, wait_consumer=0.0, overlay=0.0, wait_engine=0.0, frames=0)
         reader = threading.Thread(target=self._stage_batches, args=(video_path, skip_secs, not iterable, out_q, free_q, stop), daemon=True)
         engine = threading.Thread(target=self._run_engine, args=(out_q, done_q, stop), daemon=True)
         reader.start()
@@ -511,7 +511,9 @@ class VideoDetector:
                         actions = []                           # :158-159
                     holds.append(hold_detections)
                     acts.append(actions)
+                t2 = time.perf_counter()
                 give((cur, holds, acts))
+                u["wait_consumer"] += (time.perf_counter() - t2) * 1e6
                 cur = nxt
             give(None)
         except BaseException as e:                             # noqa: BLE001 - re-raised on the consumer's thread
