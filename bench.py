@@ -342,7 +342,7 @@ def main():
         first 16 steady-state steps (pipeline.cpp Trial: groups of 4 alternating serialized / two-stream, the faster one kept).  These steps run here,
         before the W warm-up steps, so that warm-up and timed region both run the settled schedule.  Returns (steps used, record)."""
         n = 0
-        if args.schedule != "policy":
+        if args.schedule != "policy" or w.per_frame * w.batch < 256:     # (smaller ReID passes keep two streams without a trial)
             return 0, None
         while w.pipe.schedule_trial(host_frames)["decided"] is None and n < 24:
             w.step(first + n, prefetch=True, host_frames=host_frames, prefetch2=True)
