@@ -104,3 +104,31 @@ def test_bench_geometries_stay_in_range():
     assert out.shape == (152, 152, 3) and abs(out.astype(np.float64).mean() - ref.mean()) < 1.0
     flat = np.full((11, 13, 3), 200, np.uint8)
     assert (resize_bilinear_u8(flat, (29, 31)) == 200).all()        # weights sum to 2048: constants are preserved
+
+
+def test_geometry_against_an_independent_float_bilinear():
+    """3P-2 stays unpinned against cv2 itself (not in the image), but its GEOMETRY - half-pixel sample positions, edge clamping, which
+    two source pixels and what weights - can be held to an independent implementation that IS here: torch's
+    F.interpolate(mode="bilinear", align_corners=False, antialias=False) computes the same interpolant in float.  The 8-bit
+    fixed-point path (11-bit weights, two roundings) may differ from the rounded float result by one grey level, never by more; on the
+    shapes of this path: frame -> detector input (down-scaling, non-integer ratios), crop -> 64 x 128 ReID input (up- and down-scaling),
+    an exact 2x reduction (OpenCV's INTER_AREA shortcut = the mean of four, which is also what the float interpolant gives)."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.RandomState(12)
+    for (h, w), (dw, dh) in (((480, 640), (416, 416)), ((540, 960), (608, 608)), ((1080, 1920), (608, 416)), ((173, 61), (64, 128)),
+                             ((40, 23), (64, 128)), ((64, 32), (16, 32)), ((97, 131), (200, 211))):
+        # smooth + noisy content: pure noise would hide a half-pixel shift behind its own variance
+        base = rng.randint(0, 256, (h // 8 + 2, w // 8 + 2, 3)).astype(np.float32)
+        img = np.kron(base, np.ones((8, 8, 1), np.float32))[:h, :w] * 0.8 + rng.randint(0, 52, (h, w, 3))
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        got = resize_bilinear_u8(img, (dw, dh)).astype(np.int32)
+        t = torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None]
+        ref = F.interpolate(t, size=(dh, dw), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        diff = np.abs(got - ref)
+        assert got.shape == (dh, dw, 3)
+        assert diff.max() <= 1.0 + 1e-3, ((h, w), (dw, dh), float(diff.max()))
+        assert diff.mean() < 0.3, ((h, w), (dw, dh), float(diff.mean()))
+        # a half-pixel shift of the sampling grid would show as a mean error of several grey levels on this content
+        shifted = F.interpolate(torch.roll(t, 1, dims=3), size=(dh, dw), mode="bilinear", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert np.abs(got - shifted).mean() > 3 * diff.mean() + 1.0
