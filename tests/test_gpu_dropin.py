@@ -1,7 +1,7 @@
-"""The drop-in boundary through the REFERENCE'S OWN import paths: the statements of the reference demo
-video_deepsort.py (lines 3-7 imports, 13-45 constructor sequence, 47-52 loop) are typed out below and executed against this
-package in a scratch directory holding config/yolov4.cfg, weights/yolov4.weights, weights/ckpt.t7, config/coco.names
-(synthetic, real file formats); only the video source differs (an .npy file instead of webcam 0, no window)."""
+"""The drop-in boundary through the REFERENCE'S OWN import paths: `tests/dropin_caller.py` - a caller written
+for this repo from the signature table, not from any reference script - builds Darknet / DeepSort / ActionIdentify /
+VideoDetector through `yolo3.*`, `deep_sort`, `action.*` in a scratch directory holding config/yolov4.cfg,
+weights/yolov4.weights, weights/ckpt.t7, config/coco.names (synthetic, real file formats) and an .npy video source."""
 import os
 import subprocess
 import sys
@@ -13,61 +13,7 @@ from conftest import ROOT, golden
 
 pytestmark = pytest.mark.gpu
 
-DEMO = r'''
-import logging, sys, json
-import numpy as np
-sys.path.insert(0, %(root)r)
-
-from action.action_Identify import ActionIdentify
-from action.actions import *
-from deep_sort import DeepSort
-from yolo3.detect.video_detect import VideoDetector
-from yolo3.models import Darknet
-
-if __name__ == '__main__':
-    LOG_FORMAT = "%%(asctime)s - %%(levelname)s - %%(message)s"
-    logging.basicConfig(level=logging.WARNING, format=LOG_FORMAT)
-
-    model = Darknet("config/yolov4.cfg", img_size=(608, 608))
-    model.load_darknet_weights("weights/yolov4.weights")
-    model.to("cuda:0")
-
-    tracker = DeepSort("weights/ckpt.t7",
-                       min_confidence=1,
-                       use_cuda=True,
-                       nn_budget=30,
-                       n_init=3,
-                       max_iou_distance=0.7,
-                       max_dist=0.3,
-                       max_age=30)
-
-    action_id = ActionIdentify(actions=[TakeOff(4, delta=(0, 1)),
-                                        Landing(4, delta=(2, 2)),
-                                        Glide(4, delta=(1, 2)),
-                                        FastCrossing(4, speed=0.2),
-                                        BreakInto(0, timeout=2)],
-                               max_age=30,
-                               max_size=8)
-
-    video_detector = VideoDetector(model, "config/coco.names",
-                                   thickness=2,
-                                   skip_frames=2,
-                                   thres=0.5,
-                                   class_mask=[0, 2, 4],
-                                   nms_thres=0.4,
-                                   tracker=tracker,
-                                   action_id=action_id,
-                                   half=%(half)s)
-
-    rows = []
-    for image, detections, actions in video_detector.detect("frames.npy",
-                                                      output_path="out.npy",
-                                                      real_show=False,
-                                                      skip_secs=0):
-        assert image.dtype == np.uint8 and image.shape == (270, 480, 3)
-        rows.append(None if detections is None else np.asarray(detections, np.int32).reshape(-1, 6).tolist())
-    print("ROWS", json.dumps(rows))
-'''
+CALLER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dropin_caller.py")
 
 
 def _scratch(tmp_path):
@@ -90,20 +36,20 @@ def _scratch(tmp_path):
 
 def _run_demo(tmp_path, half):
     import json
-    out = subprocess.run([sys.executable, "-c", DEMO % dict(root=ROOT, half=half)], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, CALLER, ROOT, half], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("ROWS ")][-1]
     return json.loads(line[5:])
 
 
-def test_reference_demo_statements_run_against_this_package(tmp_path):
-    """video_deepsort.py:3-7,13-52 with half=False, checked against the package's own frame-by-frame API on the same files."""
+def test_caller_through_reference_import_paths(tmp_path):
+    """The shim-path caller with half=False, checked against the package's own frame-by-frame API on the same files."""
     from yolo_deepsort_amd import _lib, loaders
     from yolo_deepsort_amd.deep_sort import DeepSort
     from yolo_deepsort_amd.detect import ImageDetector, p1p2Toxywh
     from yolo_deepsort_amd.models import Darknet
     cfg, sd, frames = _scratch(tmp_path)
-    rows = _run_demo(tmp_path, "False")
+    rows = _run_demo(tmp_path, "0")
     assert len(rows) == 6
     assert os.path.exists(tmp_path / "out.npy") and np.load(tmp_path / "out.npy").shape == (6, 270, 480, 3)
     # the same path through the package's own names, frame by frame (skip_frames=2: frames 0, 2, 4 are processed, the rest hold)
@@ -130,10 +76,10 @@ def test_reference_demo_statements_run_against_this_package(tmp_path):
     assert n_det > 0, "the synthetic head bias should let some candidates through (otherwise the loop only saw None)"
 
 
-def test_reference_demo_half_true(tmp_path):
-    """The demo's own mode (video_deepsort.py:44 half=True): runs, yields one result per frame."""
+def test_caller_half_mode(tmp_path):
+    """half=True (the mode the reference demo constructs its VideoDetector in): runs, yields one result per frame."""
     _scratch(tmp_path)
-    rows = _run_demo(tmp_path, "True")
+    rows = _run_demo(tmp_path, "1")
     assert len(rows) == 6
 
 

@@ -591,6 +591,7 @@ def test_video_generator_control_flow_vs_reference_fixture(case, batch_frames, t
                 return [None if hold_of[t] is None else np.asarray(hold_of[t], np.int32).reshape(-1, 6) for t in self.groups.pop(0)]
         pipe = Pipe()
         vd._pipe = pipe
+        vd._batchable = lambda: True                              # the stand-in tracker plays the package's DeepSort
         orig = vd._processed_batches
 
         def spy(*a, **k):
@@ -667,6 +668,7 @@ def test_batched_generator_stops_cleanly_when_the_consumer_leaves(tmp_path):
     def make(pipe):
         vd = D.VideoDetector(Model(), str(names), tracker=Tracker(), batch_frames=4)
         vd._pipe = pipe
+        vd._batchable = lambda: True                              # the stand-in tracker plays the package's DeepSort
         vd._upload_group = lambda blk, fr, h, w, bgr: blk.update(dev=Buf(), host=list(fr))
         vd._render_batch = lambda cur, holds, fps, bgr: [vd._render_host(cur["blk"]["host"][cur["slot_of"][i]], holds[i], None) for i in range(len(holds))]
         return vd
@@ -695,3 +697,46 @@ def test_batched_generator_stops_cleanly_when_the_consumer_leaves(tmp_path):
     while threading.active_count() > before and time.time() < deadline:
         time.sleep(0.05)
     assert threading.active_count() == before
+
+
+def test_batched_path_is_gated_on_the_package_tracker_and_live_captures():
+    """the default (batch_frames=None) must keep the frame-by-frame loop for a tracker that only offers update() - a
+    DeepSort around a user callable, a custom tracker - and an already-open capture without a frame count is a live source."""
+    from types import SimpleNamespace
+    from yolo_deepsort_amd.deep_sort import DeepSort, Extractor
+    from yolo_deepsort_amd.detect import VideoDetector
+
+    class Cap:                                             # what cv2.VideoCapture(0) looks like to _is_live
+        def __init__(self, n):
+            self.n = n
+
+        def isOpened(self):
+            return True
+
+        def get(self, prop):
+            assert prop == 7                               # cv2.CAP_PROP_FRAME_COUNT
+            return self.n
+
+    assert VideoDetector._is_live(Cap(0)) and VideoDetector._is_live(Cap(-1)) and not VideoDetector._is_live(Cap(250))
+    assert VideoDetector._is_live(0) and VideoDetector._is_live("rtsp://cam/1") and not VideoDetector._is_live("clip.mp4")
+
+    def vd(tracker):
+        v = object.__new__(VideoDetector)
+        v.tracker, v.image_detector = tracker, SimpleNamespace(win_size=None)
+        return v
+
+    assert not vd(None)._batchable()
+    assert not vd(SimpleNamespace(update=lambda *a: []))._batchable()                      # custom tracker: update() only
+    ds = object.__new__(DeepSort)                                                          # DeepSort around a user callable
+    ds.extractor, ds.tracker, ds.nms_max_overlap = (lambda crops: np.zeros((len(crops), 512), np.float32)), SimpleNamespace(_h=1), 1.0
+    assert not vd(ds)._batchable()
+    ex = object.__new__(Extractor)
+    ex._h = None                                                                           # (keeps __del__ quiet)
+    ds.extractor = ex
+    assert vd(ds)._batchable()
+    ds.nms_max_overlap = 0.5                                                               # tracker-side NMS reorders on the host
+    assert not vd(ds)._batchable()
+    ds.nms_max_overlap = 1.0
+    v = vd(ds)
+    v.image_detector.win_size = (416, 416)                                                 # tiled detection: frame by frame
+    assert not v._batchable()

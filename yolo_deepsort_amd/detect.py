@@ -240,7 +240,21 @@ class VideoDetector:
         through) or a network stream URL."""
         if isinstance(video_path, int):
             return True
+        if hasattr(video_path, "isOpened"):                          # an already-open capture: live unless it knows its frame count
+            try:
+                return float(video_path.get(7)) <= 0                 # cv2.CAP_PROP_FRAME_COUNT (0 / -1 for cameras and streams)
+            except Exception:
+                return True
         return isinstance(video_path, str) and (video_path.isdigit() or "://" in video_path)
+
+    def _batchable(self):
+        """The batched device pipeline drives the package's own DeepSort (its Extractor and device tracker handles); a tracker that
+        only offers update() - a DeepSort built around a user callable, any custom tracker - keeps the frame-by-frame loop."""
+        from .deep_sort import DeepSort, Extractor
+        t = self.tracker
+        return (isinstance(t, DeepSort) and isinstance(getattr(t, "extractor", None), Extractor)
+                and hasattr(t.extractor, "_h") and hasattr(getattr(t, "tracker", None), "_h")
+                and self.image_detector.win_size is None and getattr(t, "nms_max_overlap", 1) == 1)
 
     def _frames(self, video_path, skip_secs=0, transform=True):
         """RGB frames of the source (transform=False: a capture / file source's frames as decoded, BGR)."""
@@ -561,8 +575,7 @@ class VideoDetector:
     def _detect_impl(self, video_path, show_fps=True, skip_secs=0):
         # (the tracker-side NMS option reorders detections on the host, so it keeps the frame-by-frame path)
         bf = self.batch_frames if self.batch_frames is not None else (1 if self._is_live(video_path) else self.AUTO_BATCH)
-        if (bf > 1 and self.tracker is not None and self.image_detector.win_size is None
-                and getattr(self.tracker, "nms_max_overlap", 1) == 1):
+        if bf > 1 and self._batchable():
             yield from self._detect_batched(video_path, show_fps, skip_secs, bf)
             return
         hold_detections, actions, frames = None, [], 0
