@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line:
                       results are identical; the pipeline times both on its first steady-state steps and keeps the faster one -
                       config.schedule_trial carries what it measured; those steps run as set-up before the W warm-up steps)
   value_f32_math      a short run of the same workload on the exact-fp32 MFMA kernels (dtype of `value` is f16x3)
+  value_real_weights  only with --weights FILE [--ckpt FILE]: the same K steps on real files, head logits NOT injected
   value_half_mode     a short run with the detector in Darknet.half() (fp16 operands, 2-byte activations; not the metric)
   value_frame_by_frame  one frame in, one result out (batch_frames = 1, nothing enqueued ahead: the reference's own loop,
                       video_detect.py:124-157); value_frame_by_frame_lookahead1 hands the next frame over one step early
@@ -156,7 +157,8 @@ def video_detector_leg(config, B, seed, n_frames, device_overlay=True):
         elif n > warm:
             rows += 0 if detections is None else len(detections)
             assert image.shape == bgr.shape[1:]
-    dt = time.perf_counter() - t0
+            t_last = time.perf_counter()                              # the clock stops when the LAST result image is delivered: the generator's
+    dt = t_last - t0                                                  # teardown (thread joins with 0.1 s polling hand-overs) is not throughput
     u = vd.host_us
     per = {"engine: " + k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_frames", "step", "wait_consumer")}
     per.update({"consumer: " + k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_engine", "overlay")})
@@ -290,6 +292,9 @@ def main():
     ap.add_argument("--half", action="store_true", help="Darknet.half(): single-term fp16 kernels (reported under dtype f16)")
     ap.add_argument("--math", default="f16x3", choices=["f16x3", "f32"], help="conv arithmetic of the WHOLE run: f16x3 (default: split-fp16 operands, exact products, "
                                                                               "fp32 accumulate) or f32 (exact fp32 MFMA kernels; profiles of the value_f32_math leg)")
+    ap.add_argument("--weights", default=os.environ.get("YDS_WEIGHTS"), help="a real Darknet .weights file of the config's network (weights/yolov3.weights ...): adds the "
+                                                                            "UN-INJECTED leg value_real_weights (SURVEY 8d 'Weights'): same steps, the detector sees what it sees")
+    ap.add_argument("--ckpt", default=os.environ.get("YDS_CKPT"), help="a real DeepSORT ckpt.t7 for that leg (default: the synthetic state dict)")
     args = ap.parse_args()
 
     # `python bench.py --gpus N` on its own launches the N ranks itself (one process per GPU, rendezvous on 127.0.0.1);
@@ -316,16 +321,8 @@ def main():
     from yolo_deepsort_amd.workload import Workload
     _lib.init()                    # YDS_DEVICE, else LOCAL_RANK (ordinal 0 when the launcher masks one device per rank)
     lib = _lib.load()
-    ranks.connect()                # RCCL communicator on the bound device (N > 1)
 
     B, K, W = args.batch, args.steps, args.warmup
-    # A multi-GPU run must not go green on the host transport by accident: RCCL is what the N > 1 numbers are about.
-    if world > 1 and ranks.requested == "nccl" and ranks.transport != "rccl":
-        if rank == 0:
-            print(json.dumps({"error": "bench.py --gpus %d: the RCCL communicator could not be formed (%s); refusing to measure over gloo - "
-                                       "set YDS_DIST_BACKEND=gloo to run the host transport on purpose" % (world, ranks.fallback_reason)}))
-        ranks.shutdown()
-        raise SystemExit(3)
     if args.math == "f32":
         lib.yds_set_conv_math(0)
     wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
@@ -356,12 +353,49 @@ def main():
 
     # ---- the metric: frames resident in HBM
     n_set, trial = settle_schedule(wl, 0, False)
-    pl.conv_clock(reset=True)
+
+    # ---- N > 1: rank 0 ALONE first (the other ranks' GPUs idle, no communicator yet, no exchange step), so that the N-rank line explains
+    #      itself: efficiency_vs_rank0_single = value / (N x this rate).  It runs on a workload OF ITS OWN (same construction, same seed):
+    #      the job's stream and tracker state must start untouched - every stream's rows equal a single-rank run of its seed bit for bit.
+    solo = None
+    if world > 1:
+        if rank == 0:
+            w1 = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
+            w1.to_device()
+            w1.pipe.set_schedule(sched_arg)
+            n1 = 0
+            if args.schedule == "policy" and w1.per_frame * w1.batch >= 256:
+                while w1.pipe.schedule_trial(False)["decided"] is None and n1 < 24:
+                    w1.step(n1, prefetch=True)
+                    n1 += 1
+            k1 = max(3, min(K, 20))
+            for i in range(n1, n1 + W):
+                w1.step(i, prefetch=i + 1 < n1 + W)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(n1 + W, n1 + W + k1):
+                w1.step(i, prefetch=i + 1 < n1 + W + k1)
+            sync()
+            dt1 = time.perf_counter() - t0
+            solo = dict(value=round(k1 * B / dt1, 2), ms_per_step=round(dt1 / k1 * 1e3, 3), steps=k1, schedule=w1.pipe.last_schedule(),
+                        note="rank 0 alone before the communicator formed: same workload construction and steps on a workload of its own, "
+                             "no exchange step, the other GPUs idle")
+            del w1
+            sync()
+        ranks.barrier()            # (host group: the communicator does not exist yet)
+    ranks.connect()                # RCCL communicator on the bound device (N > 1)
+    # A multi-GPU run must not go green on the host transport by accident: RCCL is what the N > 1 numbers are about.
+    if world > 1 and ranks.requested == "nccl" and ranks.transport != "rccl":
+        if rank == 0:
+            print(json.dumps({"error": "bench.py --gpus %d: the RCCL communicator could not be formed (%s); refusing to measure over gloo - "
+                                       "set YDS_DIST_BACKEND=gloo to run the host transport on purpose" % (world, ranks.fallback_reason)}))
+        ranks.shutdown()
+        raise SystemExit(3)
     kept = [] if args.dump_rows else None
     own = {}
     dt, n_out = timed_steps(wl, ranks, sync, K, W, n_set, host_frames=False, keep=kept, own=own)     # n_out: rows of ALL streams (gathered on every rank)
     dt_own = own["dt"]
-    clock_ghz, clock_ms = pl.conv_clock(reset=True)              # shader clock inside the window kernels over the K timed steps (+ warm-up)
+    clock_ghz, clock_ms = 0.0, 0.0
     if kept is not None and rank == 0:
         import numpy as np
         arrays = {}
@@ -372,6 +406,7 @@ def main():
         np.savez(args.dump_rows, **arrays)
     rank_devices = ranks.gather_objects((_lib.current_device(), _lib.pci_bus_id()))
     rank_values = ranks.gather_objects(round(K * B / dt_own, 2))        # every rank's own frames/s over its own clock around the K steps
+    rank_ms = ranks.gather_objects(round(dt_own / K * 1e3, 3))          # and its own ms per step
     flops_frame = wl.flops_per_frame()
     stage = wl.pipe.stage_us()
     schedule = wl.pipe.last_schedule()
@@ -408,7 +443,9 @@ def main():
         # share the CUs and stretch every detector launch without the chip doing less (config.schedule / schedule_trial say what the
         # product picked on this box and why).
         wl.pipe.set_schedule(0)
+        pl.conv_clock(reset=True)                                 # one-wave clock probe on its own stream beside the diagnostic leg (never beside `value`)
         variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, base, peak)
+        clock_ghz, clock_ms = pl.conv_clock(reset=False)          # shader clock the chip held over that leg's W + K steps
         wl.pipe.set_schedule(sched_arg)
         if rank == 0 and dom is not None:
             note = ("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
@@ -423,8 +460,8 @@ def main():
                 # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
                 # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
                 pipeline_conv_frac=round(flops_frame * K * B / dt / 1e12 / peak, 4),
-                # the peak assumes 2.4 GHz; the chip is power limited under this load: clock sampled INSIDE the window
-                # kernels (s_memtime / s_memrealtime, one workgroup in 32) over the timed region
+                # the peak assumes 2.4 GHz; the chip is power limited under this load: clock sampled by a one-wave probe kernel on
+                # its own stream (s_memtime / s_memrealtime at both ends of this diagnostic leg; csrc/clock_probe.hip)
                 sustained_clock_ghz=round(clock_ghz, 3), nominal_clock_ghz=2.4,
                 peak_at_sustained_clock=round(dom["peak"] * clock_ghz / 2.4, 1) if clock_ghz else None,
                 frac_at_sustained_clock=round(dom["achieved"] / (dom["peak"] * clock_ghz / 2.4), 4) if clock_ghz else None)
@@ -524,6 +561,38 @@ def main():
         del wlh
         sync()
 
+    # ---- the un-injected leg (SURVEY 8d "Weights"): real .weights / ckpt.t7 files, nothing written into the head tensors
+    real, real_err = None, None
+    if args.weights:
+        wlr, dtr = None, None
+        try:
+            if not os.path.exists(args.weights) or (args.ckpt and not os.path.exists(args.ckpt)):
+                raise FileNotFoundError(args.weights if not os.path.exists(args.weights) else args.ckpt)
+            wlr = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), weights=args.weights, ckpt=args.ckpt, half=args.half)
+            wlr.to_device()
+            wlr.pipe.set_schedule(sched_arg)
+        except Exception as e:                                     # noqa: BLE001 (per-rank failure: vote before any collective, like the half leg)
+            real_err = f"{type(e).__name__}: {e}"[:300]
+            wlr = None
+        votes = ranks.gather_objects(real_err)
+        if all(v is None for v in votes):
+            nr, _ = settle_schedule(wlr, 0, False)
+            try:
+                dtr, rows_r = timed_steps(wlr, ranks, sync, K, W, nr, host_frames=False)
+            except Exception as e:                                 # noqa: BLE001 - e.g. weights whose detections include empty crops: the reference's
+                real_err = f"{type(e).__name__}: {e}"[:300]        # cv2.resize raises there too (one rank only: a multi-rank job would stop here)
+                if world > 1:
+                    raise
+                dtr = None
+        if real_err is None and dtr is not None:
+            real = dict(value=round(ranks.total_frames(K, B) / dtr, 2), tracker_rows_out=rows_r, weights=os.path.basename(args.weights),
+                        ckpt=os.path.basename(args.ckpt) if args.ckpt else "synthetic state dict", schedule=wlr.pipe.last_schedule(),
+                        note="no head-logit injection: detections are whatever these weights find in the synthetic frames")
+        elif real_err is None or any(v is not None for v in votes):
+            real_err = "; ".join(f"rank {r}: {v}" for r, v in enumerate(votes) if v is not None)[:300]
+        del wlr
+        sync()
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:      # rank 0 at N = 1 only (bench contract)
         cpu = cpu_baseline("cfg3" if args.config == "cfg4" else args.config, args.cpu_frames)
@@ -538,7 +607,9 @@ def main():
             "config": {"workload": cfg["workload"], "frames_per_step": B, "streams": world, "frame": "1920x1080x3 u8",
                        "frames_in": "resident in HBM", "tracker_rows_out": n_out, "schedule": schedule, "parallelism": f"stream-per-gpu x{world}",
                        "rank_devices": [d for d, _ in rank_devices], "rank_pci_bus_ids": [b for _, b in rank_devices],
-                       "rank_values": rank_values,
+                       "rank_values": rank_values, "rank_ms_per_step": rank_ms,
+                       **({} if solo is None else {"rank0_single": solo,
+                                                   "efficiency_vs_rank0_single": round(frames_total / dt / (world * solo["value"]), 4)}),
                        "schedule_trial": None if trial is None else dict(
                            note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds per 6 measured steps under either "
                                 "schedule on this box, per rank; `schedule` is what the timed steps then ran under",
@@ -553,6 +624,7 @@ def main():
             "value_half_mode": None if half_fps is None else round(half_fps, 2),
             **({"value_half_mode_error": half_err} if half_err else {}),
             "value_half_mode_note": "Darknet.half(): detector on single-term fp16 operands with 2-byte activations (the reference's ImageDetector(half=True)); fp16-class accuracy, not the metric",
+            **({"value_real_weights": real} if args.weights else {}), **({"value_real_weights_error": real_err} if real_err else {}),
             "value_frame_by_frame": None if fbf is None else round(fbf, 2),
             "value_frame_by_frame_lookahead1": None if fbf_ahead is None else round(fbf_ahead, 2),
             "value_frame_by_frame_note": "batch_frames = 1: one frame in, one result out, nothing enqueued ahead (video_detect.py:124-157); "

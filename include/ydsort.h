@@ -96,13 +96,6 @@ int yds_darknet_forward_u8_dev(yds_net *, const uint8_t *rgb_hwc_dev, int h, int
 const uint8_t *yds_darknet_last_frames_dev(yds_net *, int *h, int *w, int *batch);
 int yds_darknet_layer_output(yds_net *, int layer, int batch, float *nchw_host);   /* parity tests */
 int yds_darknet_get_input(yds_net *, int batch, float *nchw_host);                 /* parity tests */
-/* bench-only: overwrite head logits so the decode yields scripted boxes.
- * rows: [n,9] fp32 = head, anchor, gy, gx, tx, ty, tw, th, cls ; image selects the batch slot.
- * Applied on every following forward until cleared with n = 0. */
-int yds_darknet_set_injection(yds_net *, int image, const float *rows_host, int n, float logit);
-/* preload n_sets x batch_max injection tables (offsets: n_sets*batch_max+1 row offsets) and pick one per step */
-int yds_darknet_load_injection_sets(yds_net *, const float *rows_host, const int32_t *offsets_host, int n_sets, float logit);
-int yds_darknet_select_injection_set(yds_net *, int set);
 
 /* ---- post-processing: soft_non_max_suppression + resize_boxes ---------------------------
  * yds_nms <- yolo3/utils/model_build.py:52-137 (multi-label hard NMS, class offset 4096,
@@ -241,8 +234,6 @@ int yds_pipeline_step_host(yds_pipe *, const uint8_t *frames_host, const uint8_t
  * queue of 128 frames, video_detect.py:86) announces it here.  The host buffer must stay valid until the next
  * yds_pipeline_step_host call returns.  Three staging buffers: at most one prefetch per step. */
 int yds_pipeline_prefetch_host(yds_pipe *, const uint8_t *frames_host, int h, int w, int batch);
-/* bench-only: injection set (yds_darknet_load_injection_sets) to select before the prefetched detector pass */
-int yds_pipeline_set_next_injection(yds_pipe *, int set);
 /* Schedule of the two chip-filling kernel sequences of a step - the ReID pass of batch i and the detector pass of batch i+1
  * (no reference counterpart: video_detect.py:134-157 runs them one after the other on one frame; results do not depend on
  * the choice).  min_crops >= 0: from that many crops per batch the ReID pass is enqueued on the detector's stream, between
@@ -254,6 +245,10 @@ int yds_pipeline_set_next_injection(yds_pipe *, int set);
  * yds_pipeline_schedule_trial: what the trial of an entry (uploaded = 0: yds_pipeline_step, 1: yds_pipeline_step_host) measured -
  * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds per 6 measured steps under either schedule. */
 int yds_pipeline_set_schedule(yds_pipe *, int min_crops);
+/* Byte order of the frames handed to yds_pipeline_step / _step_host: 0 = R, G, B (default: what video_detect.py:33-36 makes of a
+ * decoded frame before the detector sees it), 1 = B, G, R as a decoder delivers them - the resize front end and the ReID crops then
+ * read channel c from byte 2 - c, the same integers as on the reversed copy the reference makes, without making it. */
+int yds_pipeline_set_frame_order(yds_pipe *, int bgr);
 int yds_pipeline_last_schedule(yds_pipe *);
 int yds_pipeline_schedule_trial(yds_pipe *, int uploaded, int *decided, double *serialized_s, double *two_stream_s);
 /* last step, microseconds: resize (device), detector (device: the detector pass alone - a ReID pass the serialized schedule puts
@@ -278,6 +273,13 @@ int yds_overlay_tracks(const uint8_t *frames_dev, const int32_t *src_slot_host, 
                        const int32_t *box_ptr_host, const uint8_t *text_host, int n_text, const int32_t *fps_host,
                        const uint8_t *font_host, int n_glyphs, int thickness, int scale, uint8_t *out_dev, uint8_t *out_host);
 int yds_swap_rb(uint8_t *frames_dev, size_t pixels);
+/* The same output stage for frames that are ALREADY in the result's channel order (a decoder's BGR, staged as delivered: round 6):
+ * nothing is copied or reversed on the device - frame src_slot_host[i] of the n_src staged frames is drawn on IN PLACE (colours land
+ * channel-reversed exactly as above) and copied to out_host + i * h*w*3 (runs of consecutive slots in one copy); the staged frames
+ * are consumed by the call.  Slots are range-checked against n_src and must be distinct. */
+int yds_overlay_tracks_bgr(uint8_t *frames_bgr_dev, int n_src, const int32_t *src_slot_host, int n_out, int h, int w, const int32_t *boxes_host,
+                           const int32_t *box_ptr_host, const uint8_t *text_host, int n_text, const int32_t *fps_host,
+                           const uint8_t *font_host, int n_glyphs, int thickness, int scale, uint8_t *out_host);
 /* Per tile-variant totals of the implicit-GEMM conv kernel (yds_conv_num_variants instantiations):
  * duration in us, launch count and algorithmic flops, measured with HIP events recorded around every
  * launch on the handle's stream.  mode 1 = zero the counters and start timing, 2 = stop, 0 = read. */
@@ -298,10 +300,12 @@ const char *yds_conv_variant_name(int variant);
  * average launch duration in us and the tile variant that was picked. */
 int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual,
                    int iters, double *avg_us, int *variant);
-/* Shader clock the chip sustained INSIDE the window-resident conv kernels since the last reset: one workgroup in 32 samples
- * s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end; *ghz = cycles / time over all samples,
- * *sampled_ms = the workgroup time that was sampled.  The dense-MFMA peaks are quoted at 2.4 GHz; under this load the chip
- * is power limited well below that, which bench.py reports next to the nominal roofline fraction. */
+/* Shader clock the chip sustained since the last call with reset != 0: a one-wave probe kernel on its own stream samples
+ * s_memtime (shader cycles) and s_memrealtime (100 MHz) when it starts and when this call stops it (it sleeps in between, and
+ * ends by itself after 30 s); *ghz = cycles / time, *sampled_ms = the interval.  reset != 0 starts the next interval, reset = 0
+ * only reads.  The product kernels carry no sampling code (rounds 3-5 sampled inside the window-resident kernels; that form is
+ * kept behind -DYDS_CLOCK_PROBE for tools/ builds).  The dense-MFMA peaks are quoted at 2.4 GHz; under this load the chip is
+ * power limited well below that, which bench.py reports next to the nominal roofline fraction. */
 int yds_conv_clock(double *ghz, double *sampled_ms, int reset);
 /* parity-test entry: one convolution through a chosen kernel variant (formats as the planner would pick them for the
  * current conv math).  x NHWC [n,h,w,cin], w [cout][kh][kw][cin] (BN already folded), res NHWC or NULL
@@ -339,6 +343,22 @@ int yds_comm_allgather_rows(yds_comm *, const int32_t *out6_host, int cap, const
                             int32_t *all_host, int *rows_needed);
 int yds_comm_allreduce_f64(yds_comm *, double *vals_host, int n, int op);
 int yds_comm_barrier(yds_comm *);
+
+/* ==== BENCH / TEST SCAFFOLDING - NOT PRODUCT API ==================================================================================
+ * Nothing below replaces a reference interface and no host-side class of the drop-in boundary calls it.  SURVEY 8(d) lets the
+ * benchmark run random-init weights by overwriting the detector's head logits so that the decode yields a scripted scene
+ * (a random-init net detects nothing, and the ReID / association stages would idle); bench.py, tools/ and the tests that replay
+ * the reference's fixtures at the benchmarked shape are the only callers.  An integrator binding the path does not bind these.
+ * `bench.py --weights/--ckpt` runs the same steps WITHOUT them on real files.
+ *   yds_darknet_set_injection: rows [n,9] fp32 = head, anchor, gy, gx, tx, ty, tw, th, cls; `image` selects the batch slot;
+ *     applied on every following forward until cleared with n = 0.
+ *   yds_darknet_load_injection_sets / _select_injection_set: preload n_sets x batch_max tables (offsets: n_sets*batch_max+1 row
+ *     offsets) and pick one per step.
+ *   yds_pipeline_set_next_injection: the set to select before the prefetched detector pass of a pipeline step. */
+int yds_darknet_set_injection(yds_net *, int image, const float *rows_host, int n, float logit);
+int yds_darknet_load_injection_sets(yds_net *, const float *rows_host, const int32_t *offsets_host, int n_sets, float logit);
+int yds_darknet_select_injection_set(yds_net *, int set);
+int yds_pipeline_set_next_injection(yds_pipe *, int set);
 
 #ifdef __cplusplus
 }

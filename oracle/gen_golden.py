@@ -1141,7 +1141,199 @@ def gen_action(ns):
     print("    action events:", sum(len(o) for o in out))
 
 
-ALL = dict(long_stream=gen_long_stream, rect=gen_rect, video_detect=gen_video_detect, action=gen_action, bench_shape=gen_bench_shape, options=gen_track_options, tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
+# ---- wide dynamic range (VERDICT r5 'next' #2): BatchNorm statistics over decades, black / saturated inputs --------------------
+WIDE_RES_CFG = """
+[net]
+channels=3
+height=64
+width=64
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=2
+pad=1
+activation=leaky
+""" + """
+[convolutional]
+batch_normalize=1
+filters=32
+size=1
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[shortcut]
+from=-3
+activation=linear
+""" * 4 + """
+[convolutional]
+batch_normalize=1
+filters=128
+size=3
+stride=2
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=255
+activation=linear
+
+[yolo]
+mask = 0,1,2
+anchors = 10,14,  23,27,  37,58,  81,82,  135,169,  344,319
+classes=80
+num=6
+"""
+WIDE_SEED = 21
+WIDE_TRACE = dict(persons=10, frame_hw=(360, 640), seed=7, occlude_frac=0.2, frames=64)
+WIDE_DS_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)
+
+
+def wide_inputs(size, seed=2):
+    """[random, all-black, saturated] images as the detector sees them (NCHW in [0, 1])."""
+    x = np.random.RandomState(seed).rand(3, 3, size, size).astype(F32)
+    x[1] = 0.0
+    x[2] = 1.0
+    return x
+
+
+def wide_reid_frame():
+    """A 360 x 640 frame of the trace's scene with a black and a white patch, and eight boxes (two inside the patches, two clipped)."""
+    sc = WIDE_TRACE
+    scene = synth.PersonScene(sc["persons"], frame_hw=sc["frame_hw"], seed=sc["seed"], occlude_frac=0.0)
+    frame = scene.frame(0).copy()
+    frame[40:200, 60:140] = 0
+    frame[40:200, 300:380] = 255
+    _, tlwh = scene.boxes(0)
+    tlwh = tlwh[:8].astype(F32).copy()
+    tlwh[0] = (62.0, 44.0, 70.0, 150.0)              # all black
+    tlwh[1] = (303.0, 45.0, 72.0, 148.0)             # all white
+    tlwh[2, :2] = (-6.5, -2.2)                       # clipped top-left
+    tlwh[3, 0] = 640 - 25.0                          # clipped right
+    return frame, tlwh
+
+
+def _layer_samples(model, torch, x, per_layer, seed):
+    """Output of every convolutional block (conv + BN + activation) of the reference model on x, `per_layer` sampled elements each."""
+    taken, hooks = {}, []
+    for i, (d, m) in enumerate(zip(model.module_defs, model.module_list)):
+        if d["type"] == "convolutional":
+            hooks.append(m.register_forward_hook(lambda mod, inp, out, i=i: taken.__setitem__(i, out.detach().numpy().copy())))
+    with torch.no_grad():
+        y = model(torch.from_numpy(x)).numpy()
+    for h in hooks:
+        h.remove()
+    out = {}
+    for i, t in taken.items():
+        idx = np.sort(np.random.RandomState(seed + i).choice(t.size, min(per_layer, t.size), replace=False)).astype(np.int64)
+        out[f"L{i}_idx"], out[f"L{i}_val"] = idx, t.reshape(-1)[idx]
+        out[f"L{i}_absmax"], out[f"L{i}_absmin"] = np.abs(t).max(), np.abs(t[t != 0]).min() if (t != 0).any() else np.float32(0)
+    return y, out
+
+
+def gen_wide_range(ns):
+    """f16x3 where it could break: yolov3-tiny 416, a 12-conv residual net and the ReID net with BatchNorm statistics over decades
+    (synth profile "wide": running_var log-uniform 1e-3 .. 1e2, gamma U(0, 2) with exact zeros, |beta| <= 3, |mean| <= 3 sigma),
+    inputs incl. an all-black and a saturated image; plus a 64-frame id trace of the reference's DeepSort with the REAL Extractor on
+    those ReID weights."""
+    import torch
+    arrays = {}
+    # (1) the residual net: every conv block sampled, three inputs
+    model, _ = _ref_darknet_profile(ns, WIDE_RES_CFG, (64, 64), WIDE_SEED, -1.0)
+    x = wide_inputs(64)
+    y, lay = _layer_samples(model, torch, x, 1024, 100)
+    arrays.update({"res_" + k: v for k, v in lay.items()})
+    arrays["res_out"] = y
+    print("    residual net: out", y.shape, "finite", bool(np.isfinite(y).all()),
+          "layer |x| ranges", [(float(lay[k.replace('_idx', '_absmin')]), float(lay[k.replace('_idx', '_absmax')])) for k in lay if k.endswith("_idx")][:12])
+    # (2) yolov3-tiny 416
+    cfg = cfgs.cfg_text("yolov3-tiny")
+    model, _ = _ref_darknet_profile(ns, cfg, (416, 416), WIDE_SEED + 1, -1.0)
+    x = wide_inputs(416)
+    y, lay = _layer_samples(model, torch, x, 512, 200)
+    arrays.update({"tiny_" + k: v for k, v in lay.items()})
+    idx = np.sort(np.random.RandomState(9).choice(y.size, 6144, replace=False)).astype(np.int64)
+    arrays["tiny_idx"], arrays["tiny_val"], arrays["tiny_shape"] = idx, y.reshape(-1)[idx], np.array(y.shape)
+    arrays["tiny_obj"] = y[:, :, 4].copy()
+    print("    tiny416: out", y.shape, "finite", bool(np.isfinite(y).all()), "|out| max", float(np.abs(y[np.isfinite(y)]).max()))
+    del model
+    # (3) the ReID net: embeddings of eight crops (a black one, a white one, two clipped)
+    sd = synth.reid_state_dict(WIDE_SEED, "wide")
+    ck = _tmp_write(b"", ".t7")
+    torch.save({"net_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, "acc": 0.0, "epoch": 0}, ck)
+    ex = ns.feature_extractor.Extractor(ck, use_cuda=False)
+    frame, tlwh = wide_reid_frame()
+    ds = ns.deep_sort.DeepSort(ex, use_cuda=False)
+    ds.height, ds.width = frame.shape[:2]
+    feats = ds._get_features(torch.from_numpy(tlwh), frame).numpy()
+    arrays["reid_tlwh"], arrays["reid_feats"] = tlwh, feats
+    g = feats @ feats.T
+    print("    reid: feats", feats.shape, "finite", bool(np.isfinite(feats).all()), "cosine between crops min/max off-diagonal",
+          float((g - 2 * np.eye(len(g))).max()), float((g + 2 * np.eye(len(g))).min()))
+    # (4) 64 frames of DeepSort.update with the real Extractor on the wide weights (boxes scripted, no detector)
+    sc = WIDE_TRACE
+    scene = synth.PersonScene(sc["persons"], frame_hw=sc["frame_hw"], seed=sc["seed"], occlude_frac=sc["occlude_frac"])
+    ds = ns.deep_sort.DeepSort(ck, use_cuda=False, **WIDE_DS_PARAMS)
+    os.unlink(ck)
+    rows, ptr, ids, ids_ptr, states = [], [0], [], [0], []
+    margins = {k: [] for k in ("cos", "gate", "iou", "lsap_eps")}
+    with MarginSpy(ns, WIDE_DS_PARAMS["max_dist"], WIDE_DS_PARAMS["max_iou_distance"]) as spy:
+        for t in range(sc["frames"]):
+            f = scene.frame(t)
+            pid, b = scene.boxes(t)
+            m = spy.begin_frame()
+            out = ds.update(torch.from_numpy(b.astype(F32)), torch.ones(len(b)), f, torch.from_numpy((pid % 3).astype(F32)))
+            r = np.array(out, dtype=np.int32).reshape(-1, 6)
+            rows.append(r)
+            ptr.append(ptr[-1] + len(r))
+            ids += [x.track_id for x in ds.tracker.tracks]
+            states += [x.state for x in ds.tracker.tracks]
+            ids_ptr.append(len(ids))
+            for k in margins:
+                margins[k].append(m[k])
+    arrays.update(trace_rows=np.concatenate(rows, 0), trace_ptr=np.array(ptr, np.int32), trace_ids=np.array(ids, np.int32),
+                  trace_ids_ptr=np.array(ids_ptr, np.int32), trace_state=np.array(states, np.int8),
+                  **{"trace_margin_" + k: np.array(v, np.float64) for k, v in margins.items()})
+    print("    trace: rows", ptr[-1], "next id", ds.tracker._next_id, "min margins",
+          {k: float(np.min(v)) for k, v in margins.items()})
+    _save("wide_range", **arrays)
+
+
+def _ref_darknet_profile(ns, cfg_text, img_size, seed, obj_bias):
+    import torch
+    cfg_path = _tmp_write(cfg_text, ".cfg")
+    w_path = _tmp_write(synth.darknet_weights_blob(cfg_text, seed, obj_bias, profile="wide"), ".weights")
+    model = ns.models.Darknet(cfg_path, img_size=img_size)
+    model.load_darknet_weights(w_path)
+    model.eval()
+    os.unlink(cfg_path)
+    os.unlink(w_path)
+    return model, torch
+
+
+
+ALL = dict(long_stream=gen_long_stream, wide=gen_wide_range, rect=gen_rect, video_detect=gen_video_detect, action=gen_action, bench_shape=gen_bench_shape, options=gen_track_options, tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
            nms=gen_nms, plumbing=gen_detect_plumbing, reid=gen_reid, kalman=gen_kalman,
            traces=gen_track_traces)
 

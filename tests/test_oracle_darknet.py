@@ -171,3 +171,38 @@ def test_tiled_detection_and_merge_quirk():
         assert np.array_equal(det[:, 5], ref[:, 5])
         np.testing.assert_allclose(det, ref, rtol=RTOL, atol=ATOL, equal_nan=True)
     assert np.isnan(g["tiled_out_b"][:, :4]).all() and not np.isnan(g["tiled_out_a"]).any()
+
+
+def test_wide_range_fixture_vs_oracle_restatement():
+    """The oracle on the wide-dynamic-range fixture (BatchNorm statistics over decades, black / saturated inputs): every sampled conv
+    block and the decoded heads of the 12-conv residual net (tests/golden/wide_range.npz, generated from the imported reference)."""
+    from oracle.gen_golden import WIDE_RES_CFG, WIDE_SEED, wide_inputs
+    g = golden("wide_range")
+    net = DarknetOracle(WIDE_RES_CFG, (64, 64), is_text=True)
+    blob = synth.darknet_weights_blob(WIDE_RES_CFG, WIDE_SEED, -1.0, profile="wide")
+    w = np.frombuffer(blob, dtype=F32, offset=20)
+    assert net.load_weights_array(w) == w.size
+    # the profile does what it says: variances over >= 4 decades, exact zeros among the gammas, |beta| up to 3
+    n0 = 32
+    beta, gamma, mean, var = (w[k * n0:(k + 1) * n0] for k in range(4))
+    assert (gamma == 0).sum() >= 1 and gamma.max() > 1.5 and np.abs(beta).max() > 2.5
+    allvar = []
+    off = 0
+    for _, cin, cout, k, bn, is_head, _ in synth.conv_shapes(WIDE_RES_CFG):
+        if bn:
+            allvar.append(w[off + 3 * cout:off + 4 * cout])
+            off += 4 * cout
+        else:
+            off += cout
+        off += cout * cin * k * k
+    allvar = np.concatenate(allvar)
+    assert allvar.min() < 3e-3 and allvar.max() > 30
+    x = wide_inputs(64)
+    out = net.forward(x, keep_layers=True)
+    n = 0
+    for key in [k for k in g.files if k.startswith("res_L") and k.endswith("_idx")]:
+        i = int(key[5:-4])
+        np.testing.assert_allclose(net.layer_outputs[i].reshape(-1)[g[key]], g[f"res_L{i}_val"], rtol=1e-4, atol=1e-4, err_msg=key)
+        n += 1
+    assert n == 12
+    np.testing.assert_allclose(out, g["res_out"], rtol=RTOL, atol=ATOL)

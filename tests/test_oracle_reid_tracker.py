@@ -165,3 +165,18 @@ def test_option_units_vs_reference_vectors():
         assert otrk.tracker_nms(g["nms_boxes"], float(g[f"nms{k}_thr"]), g[f"nms{k}_order"]) == g[f"nms{k}_pick"].tolist(), k
     with pytest.raises(ValueError):
         otrk.TrackerOracle(metric="manhattan")
+
+
+def test_reid_on_wide_range_weights():
+    """The ReID restatement on the wide-dynamic-range weights (synth profile "wide") incl. an all-black and an all-white crop."""
+    from oracle.gen_golden import WIDE_SEED, wide_reid_frame
+    g = golden("wide_range")
+    frame, tlwh = wide_reid_frame()
+    assert np.array_equal(tlwh, g["reid_tlwh"])
+    sd = synth.reid_state_dict(WIDE_SEED, "wide")
+    var = np.concatenate([v.reshape(-1) for k, v in sd.items() if k.endswith("running_var")])
+    assert var.min() < 2e-3 and var.max() > 50
+    feats = oreid.reid_forward(oreid.preprocess_crops(frame, tlwh), sd)
+    np.testing.assert_allclose(feats, g["reid_feats"], rtol=RTOL, atol=1e-5)
+    d = 1.0 - g["reid_feats"] @ g["reid_feats"].T
+    assert d[~np.eye(8, dtype=bool)].min() > 1e-3                      # the embeddings still tell the crops apart

@@ -134,6 +134,8 @@ SIGNATURES = {
     "yds_conv_timing": (_I, [_P, _I, _P, _P, _P]),
     "yds_overlay_tracks": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P, _P]),
     "yds_swap_rb": (_I, [_P, _SZ]),
+    "yds_overlay_tracks_bgr": (_I, [_P, _I, _P, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _P]),
+    "yds_pipeline_set_frame_order": (_I, [_P, _I]),
 }
 
 _lib = None

@@ -42,6 +42,10 @@ hipStream_t make_stream(bool latency_role);   // non-blocking stream; optional C
         return nullptr;                                                                        \
     }
 
+// ---- sustained shader clock beside a running workload (clock_probe.hip): one wave on its own stream ---------------
+void clock_probe_start(double max_seconds);
+void clock_probe_stop(double *ghz, double *ms);          // zeros when no probe was running
+
 // ---- device buffer ------------------------------------------------------------------------
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -132,14 +136,14 @@ void launch_inject(const View &head, int image, const float *rows_dev, int n, in
 void launch_inject_batch(const View &head, int batch, const float *table_dev, const int *offsets_dev, int max_rows, int head_index,
                          int num_classes, float logit, hipStream_t s);
 // stretch-resize uint8 HWC frames to NHWC4 fp32 in [0,1] (4th channel 0)
-void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s);
+void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s, bool bgr = false);   // bgr: frames in a decoder's B, G, R byte order
 void launch_tile_resize(const uint8_t *frame, int w, const int *tiles_dev, int n_tiles, const View &y, hipStream_t s);
 void launch_tile_boxes(const float *pred, int n_boxes, int attrs, const int *tiles_dev, const float *scale_dev, int n_tiles, float *dst,
                        hipStream_t s);
 // ReID: crop + resize to 64x128 + /255 + mean/std -> NHWC4
 // boxes: [D,5] = x1,y1,x2,y2,frame index (frames are h*w*3 bytes apart)
 void launch_crop_resize(const uint8_t *frames, int h, int w, const int *boxes5_dev, int D, const View &y,
-                        hipStream_t s);
+                        hipStream_t s, bool bgr = false);
 void launch_avgpool_l2norm(const View &x, float *out, hipStream_t s);         // [D,8,4,512] -> [D,512]
 
 }  // namespace yds

@@ -332,7 +332,7 @@ void launch_conv_win(ConvKernelArgs k, int shape, hipStream_t s);   // shape 0: 
 const char *conv_f16x3_variant_name(int v);
 void launch_conv_f16x3(ConvKernelArgs k, int variant, hipStream_t s);
 // sampled (shader cycles, 100 MHz ticks) accumulated inside the window kernels since the last reset
-void conv_win_clock(unsigned long long *cycles_ticks, bool reset);
+void conv_win_clock(unsigned long long *cycles_ticks, bool reset);   // in-kernel sampling: -DYDS_CLOCK_PROBE builds only (zeros otherwise)
 void conv_win16_clock(unsigned long long *cycles_ticks, bool reset);
 bool conv_win16_small_applicable(const ConvKernelArgs &k);           // shape 2 below
 void launch_conv_win16(ConvKernelArgs k, int shape, hipStream_t s);  // the f16x3 (default arithmetic) form on v_mfma_f32_16x16x32_f16 (conv_win16.hip)

@@ -22,7 +22,9 @@ namespace yds {
 // Sustained shader clock INSIDE the kernel: one workgroup in 32 samples the shader-cycle counter (s_memtime) and the constant
 // 100 MHz counter (s_memrealtime) at its start and end; cycles / ticks is the clock the chip really ran at while every CU
 // was busy with this kernel (it is power limited: ~1.55 GHz, not the 2.4 GHz the MFMA peak is quoted at).
+#ifdef YDS_CLOCK_PROBE
 __device__ unsigned long long yds_clk_win[2];
+#endif
 namespace {
 
 constexpr int BM = 256, NW = 8, NT = NW * 64;
@@ -65,9 +67,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
         n0 = tn * BN;
     }
     if (tid < 32) reinterpret_cast<float *>(smem + zoff)[tid] = 0.f;
+#ifdef YDS_CLOCK_PROBE
     const bool clk_sample = tid == 0 && (blockIdx.x & 31) == 0;
     unsigned long long clk_c0 = 0, clk_w0 = 0;
     if (clk_sample) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = wall_clock64(); }
+#endif
 
     const int W = p.W, G = TERMS == 4 ? p.Cin / 64 : p.Cin / 32;       // channel groups per K step
     constexpr int GROUP_BYTES = TERMS == 4 ? 256 : 128;
@@ -267,10 +271,12 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_f16x3_win(ConvKernelArgs p, int
             for (int e = 0; e < 16; ++e)
                 acc1[i][j][e] *= 1.f / A_SCALE;                       // every tier of this kernel keeps one accumulator set
     conv_epilogue<BM, BN, WM, WN, ACT, RES, TM, TN, NT, true>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);   // whole-tile staging
+#ifdef YDS_CLOCK_PROBE
     if (clk_sample) {
         atomicAdd(&yds_clk_win[0], __builtin_amdgcn_s_memtime() - clk_c0);
         atomicAdd(&yds_clk_win[1], wall_clock64() - clk_w0);
     }
+#endif
 }
 
 int window_rows(int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
@@ -293,11 +299,16 @@ template <int BN, int WM, int WN, int ACT, int RES, int TERMS> void launch_inst_
 }  // namespace
 
 void conv_win_clock(unsigned long long *cycles_ticks, bool reset) {
+#ifdef YDS_CLOCK_PROBE
     YDS_HIP(hipMemcpyFromSymbol(cycles_ticks, HIP_SYMBOL(yds_clk_win), 2 * sizeof(unsigned long long)));
     if (reset) {
         unsigned long long z[2] = {};
         YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_clk_win), z, sizeof z));
     }
+#else
+    cycles_ticks[0] = cycles_ticks[1] = 0;     // product build: no sampling inside the kernel (clock_probe.hip measures beside it)
+    (void)reset;
+#endif
 }
 
 bool conv_win_applicable(const ConvKernelArgs &k) {

@@ -30,7 +30,9 @@
 
 namespace yds {
 
+#ifdef YDS_CLOCK_PROBE
 __device__ unsigned long long yds_clk_win16[2];        // sampled (shader cycles, 100 MHz ticks) inside the kernel, see conv_win.hip
+#endif
 
 namespace {
 
@@ -70,9 +72,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv3x3_f1
         n0 = tn * BN;
     }
     if (tid < 32) reinterpret_cast<float *>(smem + zoff)[tid] = 0.f;
+#ifdef YDS_CLOCK_PROBE
     const bool clk_sample = tid == 0 && (blockIdx.x & 31) == 0;
     unsigned long long clk_c0 = 0, clk_w0 = 0;
     if (clk_sample) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = wall_clock64(); }
+#endif
 
     const int W = p.W, G = p.Cin / 32;
     const int drow = lane >> 3, dpos = lane & 7;
@@ -253,10 +257,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv3x3_f1
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc1[i][j][e] = (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     conv_epilogue16<BM, BN, WM, WN, ACT, RES, TM, TN, NT, true>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);   // whole-tile staging
+#ifdef YDS_CLOCK_PROBE
     if (clk_sample) {
         atomicAdd(&yds_clk_win16[0], __builtin_amdgcn_s_memtime() - clk_c0);
         atomicAdd(&yds_clk_win16[1], wall_clock64() - clk_w0);
     }
+#endif
 }
 
 int window_rows16(int BM, int W) { return (BM + 2 * W + 2 + 7) / 8 * 8; }
@@ -284,11 +290,16 @@ template <int BM, int BN, int WM, int WN, int ACT, int RES> void launch_inst_win
 }  // namespace
 
 void conv_win16_clock(unsigned long long *cycles_ticks, bool reset) {
+#ifdef YDS_CLOCK_PROBE
     YDS_HIP(hipMemcpyFromSymbol(cycles_ticks, HIP_SYMBOL(yds_clk_win16), 2 * sizeof(unsigned long long)));
     if (reset) {
         unsigned long long z[2] = {};
         YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_clk_win16), z, sizeof z));
     }
+#else
+    cycles_ticks[0] = cycles_ticks[1] = 0;     // product build: no sampling inside the kernel (clock_probe.hip measures beside it)
+    (void)reset;
+#endif
 }
 
 // the 128 x 64 tile with two workgroups per CU: 64-filter layers whose two windows + ring fit 80 KB and whose window is fetched by

@@ -16,7 +16,9 @@
 
 namespace yds {
 
+#ifdef YDS_CLOCK_PROBE
 __device__ unsigned long long yds_clk_win2[2];  // sustained shader clock inside the kernel: (cycles, 100 MHz ticks) of one workgroup in 32 (see conv_win.hip)
+#endif
 
 namespace {
 
@@ -47,9 +49,11 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
         n0 = tn * BN2;
     }
     if (tid < 16) reinterpret_cast<float *>(smem + zoff)[tid] = 0.f;
+#ifdef YDS_CLOCK_PROBE
     const bool clk_sample = tid == 0 && (blockIdx.x & 31) == 0;
     unsigned long long clk_c0 = 0, clk_w0 = 0;
     if (clk_sample) { clk_c0 = __builtin_amdgcn_s_memtime(); clk_w0 = wall_clock64(); }
+#endif
     const int W = p.W, G = p.Cin / 32, HG = 2 * G;               // half groups
     const int drow = lane >> 2, dpos = lane & 3;
     const int npieces = wrows / 16;
@@ -236,10 +240,12 @@ __global__ __launch_bounds__(NT2, 2) void conv3x3_f16x3_win2(ConvKernelArgs p, i
             for (int e = 0; e < 16; ++e)
                 acc1[i][j][e] = TERMS == 1 ? acc1[i][j][e] * (1.f / A_SCALE) : (acc1[i][j][e] + acc2[i][j][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
     conv_epilogue<BM2, BN2, WM, WN, ACT, RES, TM, TN, NT2, true>(p, acc1, reinterpret_cast<float *>(smem), m0, n0, tid);   // whole-tile staging
+#ifdef YDS_CLOCK_PROBE
     if (clk_sample) {
         atomicAdd(&yds_clk_win2[0], __builtin_amdgcn_s_memtime() - clk_c0);
         atomicAdd(&yds_clk_win2[1], wall_clock64() - clk_w0);
     }
+#endif
 }
 
 int window_rows2(int W) { return (BM2 + 2 * W + 2 + 15) / 16 * 16; }
@@ -269,11 +275,16 @@ bool conv_win2_applicable(const ConvKernelArgs &k) {
 }
 
 void conv_win2_clock(unsigned long long *cycles_ticks, bool reset) {
+#ifdef YDS_CLOCK_PROBE
     YDS_HIP(hipMemcpyFromSymbol(cycles_ticks, HIP_SYMBOL(yds_clk_win2), 2 * sizeof(unsigned long long)));
     if (reset) {
         unsigned long long z[2] = {};
         YDS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(yds_clk_win2), z, sizeof z));
     }
+#else
+    cycles_ticks[0] = cycles_ticks[1] = 0;     // product build: no sampling inside the kernel (clock_probe.hip measures beside it)
+    (void)reset;
+#endif
 }
 
 void launch_conv_win2(ConvKernelArgs k, hipStream_t s) {

@@ -1033,14 +1033,24 @@ int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride
 }
 int yds_conv_clock(double *ghz, double *sampled_ms, int reset) {
     YDS_API_BEGIN
+    double g = 0, ms = 0;
+#ifdef YDS_CLOCK_PROBE
+    // tools/ builds only (-DYDS_CLOCK_PROBE): the rounds 3-5 form, sampled inside the window-resident kernels
     YDS_HIP(hipDeviceSynchronize());
     unsigned long long a[2], b[2], c[2];
     yds::conv_win_clock(a, reset != 0);
     yds::conv_win2_clock(b, reset != 0);
     yds::conv_win16_clock(c, reset != 0);
     const double cycles = (double)a[0] + (double)b[0] + (double)c[0], ticks = (double)a[1] + (double)b[1] + (double)c[1];
-    if (ghz) *ghz = ticks > 0 ? cycles / ticks * 0.1 : 0.0;              // ticks are 10 ns
-    if (sampled_ms) *sampled_ms = ticks * 1e-5;
+    g = ticks > 0 ? cycles / ticks * 0.1 : 0.0;                          // ticks are 10 ns
+    ms = ticks * 1e-5;
+#else
+    // product build: a one-wave probe on its own stream (clock_probe.hip); reset = start a new interval (the probe ends by itself after 30 s)
+    yds::clock_probe_stop(&g, &ms);
+    if (reset) yds::clock_probe_start(30.0);
+#endif
+    if (ghz) *ghz = g;
+    if (sampled_ms) *sampled_ms = ms;
     YDS_API_END
 }
 int yds_conv_run(int variant, int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int res_mode, const float *x_nhwc,

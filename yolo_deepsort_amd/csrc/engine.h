@@ -188,7 +188,7 @@ public:
     void finalize();
     void embed_dev(const uint8_t *frame_dev, int h, int w, const float *tlwh_host, int D, float *out_host);
     // crops of several frames in one batch: frame_of[d] selects frames_dev + frame_of[d]*h*w*3; asynchronous
-    void embed_multi_dev(const uint8_t *frames_dev, int h, int w, const float *tlwh_host, const int *frame_of, int D);
+    void embed_multi_dev(const uint8_t *frames_dev, int h, int w, const float *tlwh_host, const int *frame_of, int D, bool bgr = false);
     void embed_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *out_host);
     void preprocess_host(const uint8_t *frame_host, int h, int w, const float *tlwh_host, int D, float *nchw_host);
     void forward_f32_host(const float *nchw, int D, float *out_host);

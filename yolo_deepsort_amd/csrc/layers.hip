@@ -397,7 +397,9 @@ __device__ __forceinline__ void resize_px(const uint8_t *base, size_t row_bytes,
     }
 }
 
-__global__ void resize_u8_kernel(const uint8_t *frames, int N, int H, int W, float *y, int Ho, int Wo, int ldy) {
+// bgr: the frames hold B, G, R bytes (a decoder's order): output channel c reads source byte 2 - c - the same integers as resizing the
+// channel-reversed frame (video_detect.py:33-36 reverses on the host first), without the reversed copy
+__global__ void resize_u8_kernel(const uint8_t *frames, int N, int H, int W, float *y, int Ho, int Wo, int ldy, int bgr) {
     const size_t total = (size_t)N * Ho * Wo;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int ox = idx % Wo;
@@ -406,13 +408,14 @@ __global__ void resize_u8_kernel(const uint8_t *frames, int N, int H, int W, flo
         int n = t / Ho;
         float o[3];
         resize_px(frames + (size_t)n * H * W * 3, (size_t)W * 3, H, W, Ho, Wo, oy, ox, o);
+        if (bgr) { const float t = o[0]; o[0] = o[2]; o[2] = t; }
         *reinterpret_cast<float4 *>(y + idx * ldy) = make_float4(__fdiv_rn(o[0], 255.f), __fdiv_rn(o[1], 255.f), __fdiv_rn(o[2], 255.f), 0.f);
     }
 }
 
-void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s) {
+void launch_resize_u8(const uint8_t *frames, int n, int h, int w, const View &y, hipStream_t s, bool bgr) {
     if (y.c != 4 || y.ld != 4) fail("resize: destination must be NHWC4");
-    hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for((size_t)n * y.h * y.w)), dim3(256), 0, s, frames, n, h, w, y.p, y.h, y.w, y.ld);
+    hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for((size_t)n * y.h * y.w)), dim3(256), 0, s, frames, n, h, w, y.p, y.h, y.w, y.ld, bgr ? 1 : 0);
     YDS_HIP(hipGetLastError());
 }
 
@@ -462,7 +465,7 @@ void launch_tile_boxes(const float *pred, int n_boxes, int attrs, const int *til
     YDS_HIP(hipGetLastError());
 }
 
-__global__ void crop_resize_kernel(const uint8_t *frames, int H, int W, const int *boxes, int D, float *y, int Ho, int Wo) {
+__global__ void crop_resize_kernel(const uint8_t *frames, int H, int W, const int *boxes, int D, float *y, int Ho, int Wo, int bgr) {
     const size_t total = (size_t)D * Ho * Wo;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         int ox = idx % Wo;
@@ -474,16 +477,17 @@ __global__ void crop_resize_kernel(const uint8_t *frames, int H, int W, const in
         const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
         float o[3];
         resize_px(frame + ((size_t)y1 * W + x1) * 3, (size_t)W * 3, ch, cw, Ho, Wo, oy, ox, o);
+        if (bgr) { const float t = o[0]; o[0] = o[2]; o[2] = t; }       // (BGR frames: see resize_u8_kernel)
 #pragma unroll
         for (int c = 0; c < 3; ++c) o[c] = __fdiv_rn(__fsub_rn(__fdiv_rn(o[c], 255.f), mean[c]), stdv[c]);
         *reinterpret_cast<float4 *>(y + idx * 4) = make_float4(o[0], o[1], o[2], 0.f);
     }
 }
 
-void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyxy_dev, int D, const View &y, hipStream_t s) {   // boxes: [D,5]
+void launch_crop_resize(const uint8_t *frame, int h, int w, const int *boxes_xyxy_dev, int D, const View &y, hipStream_t s, bool bgr) {   // boxes: [D,5]
     if (D == 0) return;
     hipLaunchKernelGGL(crop_resize_kernel, dim3(grid_for((size_t)D * y.h * y.w)), dim3(256), 0, s, frame, h, w, boxes_xyxy_dev, D, y.p,
-                       y.h, y.w);
+                       y.h, y.w, bgr ? 1 : 0);
     YDS_HIP(hipGetLastError());
 }
 

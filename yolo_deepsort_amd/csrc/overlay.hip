@@ -11,6 +11,7 @@
 // owns a frame and separates the steps with barriers.
 #include "common.h"
 
+#include <mutex>
 #include <vector>
 
 #include "ydsort.h"
@@ -87,9 +88,10 @@ __device__ __forceinline__ void put_text(uint8_t *img, int H, int W, const uint8
     }
 }
 
-__global__ __launch_bounds__(256) void overlay_draw_kernel(uint8_t *out, size_t frame_bytes, DrawArgs a) {
+// slots != NULL: draw IN PLACE on frame slots[i] of `out` (frames that are already in the result's channel order)
+__global__ __launch_bounds__(256) void overlay_draw_kernel(uint8_t *out, size_t frame_bytes, DrawArgs a, const int *slots) {
     const int i = blockIdx.x, H = a.H, W = a.W;
-    uint8_t *img = out + (size_t)i * frame_bytes;
+    uint8_t *img = out + (size_t)(slots ? slots[i] : i) * frame_bytes;
     const int lo = a.thickness / 2, hi = (a.thickness - 1) / 2, fh = 7 * a.scale;
     for (int k = a.box_ptr[i]; k < a.box_ptr[i + 1]; ++k) {
         const int *b = a.boxes + (size_t)k * 8;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(256) void overlay_draw_kernel(uint8_t *out, size_t 
 // just uploaded, the consumer thread renders the previous one.  Each gets its own stream and its own scratch, created once
 // (function-local statics: initialisation is thread safe) - a swap never queues behind a 200 MB result copy.
 struct OverlayState {
+    std::mutex mu;                       // one render at a time: the scratch below is shared by every caller of this process
     hipStream_t stream = nullptr;
     DevBuf<int> boxes, box_ptr, fps, slots;
     DevBuf<uint8_t> text, font;
@@ -159,22 +162,23 @@ int yds_swap_rb(uint8_t *frames_dev, size_t pixels) {
     YDS_API_END
 }
 
-int yds_overlay_tracks(const uint8_t *frames_dev, const int32_t *src_slot_host, int n_out, int h, int w, const int32_t *boxes_host,
-                       const int32_t *box_ptr_host, const uint8_t *text_host, int n_text, const int32_t *fps_host, const uint8_t *font_host,
-                       int n_glyphs, int thickness, int scale, uint8_t *out_dev, uint8_t *out_host) {
-    YDS_API_BEGIN
-    if (n_out <= 0) return 0;
-    if (!frames_dev || !src_slot_host || !box_ptr_host || !fps_host || !font_host || !out_dev) yds::fail("overlay: NULL argument");
+namespace {
+// validation + upload of the draw tables shared by both entries; returns the kernel's argument block
+yds::DrawArgs overlay_tables(yds::OverlayState &s, const int32_t *src_slot_host, int n_src, int n_out, int h, int w, const int32_t *boxes_host,
+                             const int32_t *box_ptr_host, const uint8_t *text_host, int n_text, const int32_t *fps_host, const uint8_t *font_host,
+                             int n_glyphs, int thickness, int scale) {
+    if (!src_slot_host || !box_ptr_host || !fps_host || !font_host) yds::fail("overlay: NULL argument");
     if (h < 1 || w < 1 || scale < 1 || n_glyphs < 1) yds::fail("overlay: bad geometry (h %d, w %d, scale %d, glyphs %d)", h, w, scale, n_glyphs);
-    yds::OverlayState &s = yds::state();
     const int total = box_ptr_host[n_out];
     if (total < 0 || (total > 0 && !boxes_host)) yds::fail("overlay: bad box table");
     for (int k = 0; k < total; ++k) {
         const int32_t *b = boxes_host + (size_t)k * 8;
         if (b[6] > 0 && (b[5] < 0 || b[5] + b[6] > n_text)) yds::fail("overlay: label of box %d outside the text buffer", k);
     }
-    for (int i = 0; i < n_out; ++i)
+    for (int i = 0; i < n_out; ++i) {
         if (fps_host[2 * i + 1] > 0 && (fps_host[2 * i] < 0 || fps_host[2 * i] + fps_host[2 * i + 1] > n_text)) yds::fail("overlay: FPS text of frame %d outside the text buffer", i);
+        if (src_slot_host[i] < 0 || (n_src > 0 && src_slot_host[i] >= n_src)) yds::fail("overlay: frame %d reads slot %d of %d staged frames", i, src_slot_host[i], n_src);
+    }
     for (int k = 0; k < n_text; ++k)
         if (text_host[k] >= n_glyphs) yds::fail("overlay: glyph code %d outside the font (%d glyphs)", (int)text_host[k], n_glyphs);
     s.boxes.upload(boxes_host, (size_t)std::max(total, 1) * 8 * (total > 0), s.stream);
@@ -183,15 +187,54 @@ int yds_overlay_tracks(const uint8_t *frames_dev, const int32_t *src_slot_host, 
     s.slots.upload(src_slot_host, (size_t)n_out, s.stream);
     s.text.upload(text_host, (size_t)n_text, s.stream);
     s.font.upload(font_host, (size_t)n_glyphs * 7, s.stream);
+    return yds::DrawArgs{s.boxes.p, s.box_ptr.p, s.text.p, s.fps.p, s.font.p, h, w, thickness, scale};
+}
+}  // namespace
+
+int yds_overlay_tracks(const uint8_t *frames_dev, const int32_t *src_slot_host, int n_out, int h, int w, const int32_t *boxes_host,
+                       const int32_t *box_ptr_host, const uint8_t *text_host, int n_text, const int32_t *fps_host, const uint8_t *font_host,
+                       int n_glyphs, int thickness, int scale, uint8_t *out_dev, uint8_t *out_host) {
+    YDS_API_BEGIN
+    if (n_out <= 0) return 0;
+    if (!frames_dev || !out_dev) yds::fail("overlay: NULL argument");
+    yds::OverlayState &s = yds::state();
+    std::lock_guard<std::mutex> lock(s.mu);                      // held until the stream has drained: the scratch is shared
+    const yds::DrawArgs a = overlay_tables(s, src_slot_host, 0, n_out, h, w, boxes_host, box_ptr_host, text_host, n_text, fps_host, font_host, n_glyphs, thickness, scale);
     const size_t frame_bytes = (size_t)h * w * 3;
     const int aligned = frame_bytes % 12 == 0 && ((uintptr_t)frames_dev % 4) == 0 && ((uintptr_t)out_dev % 4) == 0;
     const unsigned bx = (unsigned)std::min<size_t>((frame_bytes / 12 + 255) / 256 + 1, 2048);
     yds::overlay_copy_kernel<<<dim3(bx, n_out), 256, 0, s.stream>>>(frames_dev, s.slots.p, out_dev, frame_bytes, aligned);
     YDS_HIP(hipGetLastError());
-    yds::DrawArgs a{s.boxes.p, s.box_ptr.p, s.text.p, s.fps.p, s.font.p, h, w, thickness, scale};
-    yds::overlay_draw_kernel<<<n_out, 256, 0, s.stream>>>(out_dev, frame_bytes, a);
+    yds::overlay_draw_kernel<<<n_out, 256, 0, s.stream>>>(out_dev, frame_bytes, a, nullptr);
     YDS_HIP(hipGetLastError());
     if (out_host) YDS_HIP(hipMemcpyAsync(out_host, out_dev, frame_bytes * n_out, hipMemcpyDeviceToHost, s.stream));
+    YDS_HIP(hipStreamSynchronize(s.stream));
+    YDS_API_END
+}
+
+int yds_overlay_tracks_bgr(uint8_t *frames_bgr_dev, int n_src, const int32_t *src_slot_host, int n_out, int h, int w, const int32_t *boxes_host,
+                           const int32_t *box_ptr_host, const uint8_t *text_host, int n_text, const int32_t *fps_host, const uint8_t *font_host,
+                           int n_glyphs, int thickness, int scale, uint8_t *out_host) {
+    YDS_API_BEGIN
+    if (n_out <= 0) return 0;
+    if (!frames_bgr_dev || !out_host || n_src < 1) yds::fail("overlay: NULL argument");
+    yds::OverlayState &s = yds::state();
+    std::lock_guard<std::mutex> lock(s.mu);
+    const yds::DrawArgs a = overlay_tables(s, src_slot_host, n_src, n_out, h, w, boxes_host, box_ptr_host, text_host, n_text, fps_host, font_host, n_glyphs, thickness, scale);
+    for (int i = 0; i < n_out; ++i)
+        for (int j = 0; j < i; ++j)
+            if (src_slot_host[i] == src_slot_host[j]) yds::fail("overlay: frames %d and %d would be drawn on the same staged slot %d", j, i, src_slot_host[i]);
+    const size_t frame_bytes = (size_t)h * w * 3;
+    yds::overlay_draw_kernel<<<n_out, 256, 0, s.stream>>>(frames_bgr_dev, frame_bytes, a, s.slots.p);
+    YDS_HIP(hipGetLastError());
+    // results leave in the caller's frame order: runs of consecutive slots go out as one copy (all of them when every frame was processed)
+    for (int i = 0; i < n_out;) {
+        int j = i + 1;
+        while (j < n_out && src_slot_host[j] == src_slot_host[j - 1] + 1) ++j;
+        YDS_HIP(hipMemcpyAsync(out_host + (size_t)i * frame_bytes, frames_bgr_dev + (size_t)src_slot_host[i] * frame_bytes, frame_bytes * (size_t)(j - i),
+                               hipMemcpyDeviceToHost, s.stream));
+        i = j;
+    }
     YDS_HIP(hipStreamSynchronize(s.stream));
     YDS_API_END
 }

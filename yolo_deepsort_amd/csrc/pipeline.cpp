@@ -141,7 +141,7 @@ public:
             if (stage[b].p && frames_dev == stage[b].p && hipEventQuery(up_done[b]) != hipSuccess)
                 YDS_HIP(hipStreamWaitEvent(net->stream, up_done[b], 0));   // (only while the copy is still running: see step())
         YDS_HIP(hipEventRecord(e0[k], net->stream));
-        launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream);
+        launch_resize_u8(frames_dev, batch, h, w, net->input_view(batch), net->stream, frames_bgr);
         YDS_HIP(hipEventRecord(e1[k], net->stream));
         if (const int sl = slot_of(frames_dev); sl >= 0) { YDS_HIP(hipEventRecord(rd_det[sl], net->stream)); rd_det_set[sl] = true; }
         head_split = split && net->forward_resized_part(batch, 0);
@@ -236,7 +236,7 @@ public:
             reid->stream = d.reid_on;
             if (reid_last_on && reid_last_on != d.reid_on) reid->sync_before_regrow = reid_last_on;
             if (inside_pass >= 0) YDS_HIP(hipEventRecord(e_r0[inside_pass], d.reid_on));
-            reid->embed_multi_dev(d.frames, h, w, d.tlwh.data(), d.frame_of.data(), (int)d.payload.size());
+            reid->embed_multi_dev(d.frames, h, w, d.tlwh.data(), d.frame_of.data(), (int)d.payload.size(), frames_bgr);
             reid->sync_before_regrow = nullptr;
             if (inside_pass >= 0) { YDS_HIP(hipEventRecord(e_r1[inside_pass], d.reid_on)); reid_in_pass[inside_pass] = true; }
             YDS_HIP(hipEventRecord(ev_reid_done, d.reid_on));
@@ -422,6 +422,7 @@ public:
     hipEvent_t e_r0[2] = {}, e_r1[2] = {};     // around a ReID pass enqueued inside the detector pass of NMS slot k
     bool reid_in_pass[2] = {false, false};
     bool last_serial = false;          // schedule of the last step
+    bool frames_bgr = false;           // yds_pipeline_set_frame_order: the frames handed over hold B, G, R bytes (a decoder's order)
     int head_slot = 0;                 // NMS slot of the pass whose head was enqueued last
     bool head_split = false, head_stale = false;
     float stage_us[5] = {0, 0, 0, 0, 0};
@@ -464,6 +465,11 @@ int yds_pipeline_prefetch_host(yds_pipe *p, const uint8_t *frames_host, int h, i
 int yds_pipeline_set_next_injection(yds_pipe *p, int set) {
     YDS_API_BEGIN
     p->p->next_inject_set = set;
+    YDS_API_END
+}
+int yds_pipeline_set_frame_order(yds_pipe *p, int bgr) {
+    YDS_API_BEGIN
+    p->p->frames_bgr = bgr != 0;
     YDS_API_END
 }
 int yds_pipeline_set_schedule(yds_pipe *p, int min_crops) {

@@ -230,7 +230,7 @@ void ReidNet::embed_dev(const uint8_t *frame_dev, int h, int w, const float *tlw
     YDS_HIP(hipStreamSynchronize(stream));
 }
 
-void ReidNet::embed_multi_dev(const uint8_t *frames_dev, int h, int w, const float *tlwh_host, const int *frame_of, int D) {
+void ReidNet::embed_multi_dev(const uint8_t *frames_dev, int h, int w, const float *tlwh_host, const int *frame_of, int D, bool bgr) {
     if (D == 0) return;
     if (!ready) fail("reid: weights not loaded (yds_reid_finalize)");
     reserve(D);
@@ -250,7 +250,7 @@ void ReidNet::embed_multi_dev(const uint8_t *frames_dev, int h, int w, const flo
     }
     memcpy(boxes_pin[t], boxes_host.data(), boxes_host.size() * sizeof(int));
     View x0; x0.p = in.p; x0.n = D; x0.h = CROP_H; x0.w = CROP_W; x0.c = 4; x0.ld = 4;
-    launch_crop_resize(frames_dev, h, w, boxes_pin[t], D, x0, stream);
+    launch_crop_resize(frames_dev, h, w, boxes_pin[t], D, x0, stream, bgr);
     forward(D);
 }
 

@@ -382,8 +382,9 @@ class VideoDetector:
 
     @staticmethod
     def _upload_group(blk, frames, h, w, bgr):
-        """The device side of the reader thread: `frames` (slot order) -> the block's pinned staging array -> its HBM buffer; a BGR
-        source is channel-swapped there (yds_swap_rb).  blk["dev"] / blk["pin"] are (re)allocated when the group outgrows them."""
+        """The device side of the reader thread: `frames` (slot order) -> the block's pinned staging array -> its HBM buffer, in the
+        source's own channel order (round 6: a BGR source is no longer swapped on the device - Pipeline.set_frame_order makes the
+        front end read it as it is).  blk["dev"] / blk["pin"] are (re)allocated when the group outgrows them."""
         from . import _lib
         lib = _lib.load()
         nbytes = len(frames) * h * w * 3
@@ -394,8 +395,7 @@ class VideoDetector:
         for slot, f in enumerate(frames):
             np.copyto(stage[slot], f)
         _lib.check(lib.yds_memcpy_h2d(blk["dev"].ptr, _lib.ptr(stage), nbytes))
-        if bgr:
-            _lib.check(lib.yds_swap_rb(blk["dev"].ptr, len(frames) * h * w))
+        blk["n"] = len(frames)            # (a BGR source stays BGR in HBM: the pipeline reads it in that order, the output stage draws on it)
 
     def _render_batch(self, cur, holds, fps_texts, bgr):
         """Output stage of one staged batch: a list of BGR frames in group order.  Device form: csrc/overlay.hip over the frames in
@@ -405,7 +405,8 @@ class VideoDetector:
             from .label_draw import DeviceOverlay
             if getattr(self, "_overlay", None) is None:
                 self._overlay = DeviceOverlay(self.label_drawer)
-            return self._overlay.render(cur["blk"]["dev"].offset(0), cur["slot_of"], h, w, holds, fps_texts)
+            return self._overlay.render(cur["blk"]["dev"].offset(0), cur["slot_of"], h, w, holds, fps_texts,
+                                        bgr_frames=cur["blk"].get("n", n) if bgr else 0)
         stage = cur["blk"]["pin"].array[:n * h * w * 3].reshape(n, h, w, 3)
         if bgr:
             stage = stage[..., ::-1]
@@ -428,6 +429,8 @@ class VideoDetector:
             self._pipe = pl.Pipeline(det.model, self.tracker, det.thres, det.nms_thres, class_mask=self.class_mask)
         self._batch_now = bf
         iterable = hasattr(video_path, "__iter__") and not isinstance(video_path, (str, bytes)) and not hasattr(video_path, "isOpened")
+        if hasattr(self._pipe, "set_frame_order"):
+            self._pipe.set_frame_order(not iterable)              # a capture / file source is staged as the decoder's BGR
         # Three threads, two hand-overs: reader (stage + upload) -> engine (pipeline steps, hold / action bookkeeping in frame order)
         # -> this generator's thread (output stage + yield).  The engine calls step(i + 1) while batch i is rendered and consumed:
         # with the output stage on the engine's thread the device idled for its 6 ms per batch (1193 against 1605 frames/s).

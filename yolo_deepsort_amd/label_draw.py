@@ -198,20 +198,24 @@ class DeviceOverlay:
         return blk
 
     def _label(self, tid, cls):
-        key = (tid, cls)
+        # id2label is consulted on EVERY frame like the host path (label_draw.py:174-176 of the reference): a name given to a track
+        # after it was first drawn shows from the next frame on; the cache only saves the glyph encoding of an unchanged string
+        d = self.drawer
+        name = d.id2label[str(tid)] if d.id2label is not None and str(tid) in d.id2label else d.classes[cls]
+        key = (tid, name)
         codes = self._labels.get(key)
         if codes is None:
-            d = self.drawer
-            name = d.id2label[str(tid)] if d.id2label is not None and str(tid) in d.id2label else d.classes[cls]
             codes = self._labels[key] = encode_text(str(tid) + ":" + name)
             if len(self._labels) > 100000:
                 self._labels.clear()
         return codes
 
-    def render(self, frames_dev, src_slots, h, w, holds, fps_texts=None, only_rect=False):
+    def render(self, frames_dev, src_slots, h, w, holds, fps_texts=None, only_rect=False, bgr_frames=0):
         """frames_dev: device pointer of uint8 RGB frames, h*w*3 bytes apart; output i shows frame src_slots[i] with the tracker
         rows holds[i] (int32 [m,6], or None / empty: nothing drawn).  Returns a list of BGR uint8 [h,w,3] arrays (views of one
-        pinned block that stays alive as long as any of them does)."""
+        pinned block that stays alive as long as any of them does).
+        bgr_frames = n > 0: the n staged frames are ALREADY BGR (a decoder's order): they are drawn on in place and copied out - no
+        reversed device copy (yds_overlay_tracks_bgr); the staged frames are consumed."""
         from . import _lib
         n = len(holds)
         if n == 0:
@@ -245,10 +249,17 @@ class DeviceOverlay:
         ptr_a = np.ascontiguousarray(ptr, dtype=np.int32)
         slots = np.ascontiguousarray(src_slots, dtype=np.int32)
         nbytes = n * h * w * 3
-        if self._out_dev is None or self._out_dev.nbytes < nbytes:
-            self._out_dev = _lib.DeviceBuffer(nbytes)
         blk = self._pinned(nbytes)
         scale = max(1, int(round(2 * (h / 1000.))))                      # draw_rects_and_labels' font_size = img.shape[0] / 1000.
+        if bgr_frames:
+            _lib.check(_lib.load().yds_overlay_tracks_bgr(frames_dev, int(bgr_frames), _lib.ptr(slots), n, h, w, _lib.ptr(boxes_a), _lib.ptr(ptr_a),
+                                                          _lib.ptr(text), toff, _lib.ptr(fps), _lib.ptr(self.font), len(self.font),
+                                                          int(d.thickness), scale, blk.ptr))
+            out = np.asarray(blk)[:nbytes].reshape(n, h, w, 3)
+            del blk
+            return [out[i] for i in range(n)]
+        if self._out_dev is None or self._out_dev.nbytes < nbytes:
+            self._out_dev = _lib.DeviceBuffer(nbytes)
         _lib.check(_lib.load().yds_overlay_tracks(frames_dev, _lib.ptr(slots), n, h, w, _lib.ptr(boxes_a), _lib.ptr(ptr_a), _lib.ptr(text), toff,
                                                   _lib.ptr(fps), _lib.ptr(self.font), len(self.font), int(d.thickness), scale,
                                                   self._out_dev.ptr, blk.ptr))

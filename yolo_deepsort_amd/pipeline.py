@@ -51,6 +51,10 @@ class Pipeline:
                                                       self.cap, _lib.ptr(counts)))
         return [None if counts[b] < 0 else out[b, :counts[b]].copy() for b in range(batch)]
 
+    def set_frame_order(self, bgr):
+        """bgr=True: the frames handed to step / step_host are B, G, R as a decoder delivers them (read in place, no reversed copy)."""
+        _lib.check(_lib.load().yds_pipeline_set_frame_order(self._h, 1 if bgr else 0))
+
     def prefetch_host(self, frames):
         """Start uploading a batch that a LATER step_host call will receive (one per step; the array must stay alive and
         unchanged until the next step_host call returns)."""

@@ -59,18 +59,57 @@ def conv_shapes(cfg_text):
     return out
 
 
-def darknet_weights_blob(cfg_text, seed=0, obj_bias=-4.0, num_classes=80):
+def _wide_bn(rng, c):
+    """BatchNorm statistics over the range a trained net shows (VERDICT r5 'next' #2): running_var log-uniform over 1e-3 .. 1e2,
+    gamma ~ U(0, 2) with one channel in 16 EXACTLY zero, |beta| <= 3, |running_mean| <= 3 standard deviations.  Returns
+    (beta, gamma, mean, var, row): row[c] = sqrt(var[c]) * m[c] is the standard deviation the conv row of channel c gives its
+    output on an input of unit second moment, so that var[c] IS (up to the mismatch m[c], log-uniform over two decades) the variance
+    of what the layer normalises - as in a trained net, where running_var tracks the real pre-BN variance; unit-gain rows under
+    var = 1e-3 would gain 30x per layer instead, which no trained net does and fp32 itself does not survive for a dozen layers.
+    m is normalised per layer to mean(gamma^2 m^2) = 2: with the activation halving the power, what the input contributes passes at
+    unit gain (He's criterion) while beta and mean add a constant ~3.5 per layer - the second moment grows linearly with depth
+    (rms ~7 after 13 layers), channel magnitudes inside a layer span 1e-3 .. 1e2."""
+    var = (10.0 ** rng.uniform(-3.0, 2.0, c)).astype(F32)
+    gamma = rng.uniform(0.0, 2.0, c).astype(F32)
+    gamma[rng.permutation(c)[:max(1, c // 16)]] = 0.0
+    beta = rng.uniform(-3.0, 3.0, c).astype(F32)
+    mean = (rng.uniform(-3.0, 3.0, c) * np.sqrt(var)).astype(F32)
+    m = 10.0 ** rng.uniform(-1.5, 0.5, c)
+    m *= np.sqrt(2.0 / np.mean(gamma.astype(np.float64) ** 2 * m ** 2))
+    return beta, gamma, mean, var, np.sqrt(var.astype(np.float64)) * m
+
+
+def darknet_weights_blob(cfg_text, seed=0, obj_bias=-4.0, num_classes=80, profile="unit"):
     """Synthetic ``.weights`` file bytes: 5xint32 header then, per conv block,
     [beta, gamma, mean, var] (BN) or [bias], then W[cout,cin,k,k] (fp32).
 
-    conv W ~ N(0, 2/(k*k*cin)) (N(0, 1/cin) for the linear heads); gamma ~
+    profile "unit" (bench.py, most fixtures): conv W ~ N(0, 2/(k*k*cin)) (N(0, 1/cin) for the linear heads); gamma ~
     U(.8,1.2); beta, mean ~ N(0,.1); var ~ U(.8,1.25), so each conv block has
     unit gain on average; the conv feeding a shortcut gets gamma/4 so 23
     residual units do not blow activations up (a trained net's BN statistics do
     the same job).  Head (pre-yolo) convs get objectness bias ``obj_bias`` so
-    candidates are sparse."""
+    candidates are sparse.
+    profile "wide" (tests/golden/wide_range.npz): BatchNorm statistics over decades, see _wide_bn; the first layer's rows
+    assume the image's second moment 1/3, the others 1 (see _wide_bn)."""
     rng = np.random.RandomState(seed)
     parts = [np.array([0, 2, 0, 0, 0], dtype=np.int32).tobytes()]
+    if profile == "wide":
+        for n, (_, cin, cout, k, bn, is_head, pre_short) in enumerate(conv_shapes(cfg_text)):
+            s_in = 1.0 / 3.0 if n == 0 else (1.0 + 3.5 * n if is_head else 1.0)       # heads: about unit-rms logits
+            if bn:
+                beta, gamma, mean, var, row = _wide_bn(rng, cout)
+                parts += [beta.tobytes(), gamma.tobytes(), mean.tobytes(), var.tobytes()]
+            else:
+                bias = (rng.randn(cout) * 0.1).astype(F32)
+                if is_head:
+                    bias[4::num_classes + 5] = obj_bias
+                parts.append(bias.tobytes())
+                row = np.ones(cout)
+            w = rng.randn(cout, cin * k * k) * (row / np.sqrt(k * k * cin * s_in))[:, None]
+            parts.append(w.astype(F32).tobytes())
+        return b"".join(parts)
+    if profile != "unit":
+        raise ValueError(profile)
     for _, cin, cout, k, bn, is_head, pre_short in conv_shapes(cfg_text):
         if bn:
             beta = (rng.randn(cout) * 0.1).astype(F32)
@@ -95,18 +134,34 @@ REID_STAGES = (("layer1", 64, 64, False), ("layer2", 64, 128, True),
                ("layer3", 128, 256, True), ("layer4", 256, 512, True))
 
 
-def reid_state_dict(seed=0):
+def reid_state_dict(seed=0, profile="unit"):
     """Seeded synthetic ReID weights with the ckpt.t7 ``net_dict`` key set (130
-    tensors incl. the unused classifier, reference deep_sort/deep/model.py:48-80)."""
+    tensors incl. the unused classifier, reference deep_sort/deep/model.py:48-80).
+    profile "wide": every BatchNorm with _wide_bn's statistics (a conv's rows are drawn when its BatchNorm is)."""
     rng = np.random.RandomState(seed)
     sd = {}
+    wide = profile == "wide"
+    if profile not in ("unit", "wide"):
+        raise ValueError(profile)
+    pending = {}
 
     def conv(name, co, ci, k, bias=False):
-        sd[name + ".weight"] = (rng.randn(co, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(F32)
+        if wide:
+            pending["conv"] = (name, co, ci, k)                      # drawn by the bn() that follows (every conv here has one)
+        else:
+            sd[name + ".weight"] = (rng.randn(co, ci, k, k) * np.sqrt(2.0 / (ci * k * k))).astype(F32)
         if bias:
             sd[name + ".bias"] = (rng.randn(co) * 0.1).astype(F32)
 
     def bn(name, c, damp=1.0):
+        if wide:
+            beta, gamma, mean, var, row = _wide_bn(rng, c)
+            if "conv" in pending:
+                cname, co, ci, k = pending.pop("conv")
+                sd[cname + ".weight"] = (rng.randn(co, ci, k, k) * (row / np.sqrt(ci * k * k))[:, None, None, None]).astype(F32)
+            sd[name + ".weight"], sd[name + ".bias"], sd[name + ".running_mean"], sd[name + ".running_var"] = gamma, beta, mean, var
+            sd[name + ".num_batches_tracked"] = np.array(0, dtype=np.int64)
+            return
         sd[name + ".weight"] = (rng.uniform(0.8, 1.2, c) * damp).astype(F32)
         sd[name + ".bias"] = (rng.randn(c) * 0.1).astype(F32)
         sd[name + ".running_mean"] = (rng.randn(c) * 0.1).astype(F32)

@@ -24,21 +24,27 @@ CONF_THRES, NMS_THRES, CLASS_MASK = 0.5, 0.4, [0, 2, 4]
 
 
 class Workload:
-    def __init__(self, config, batch, seed=0, n_distinct=None, half=False, long_occlude=None, pingpong=True):
+    def __init__(self, config, batch, seed=0, n_distinct=None, half=False, long_occlude=None, pingpong=True, weights=None, ckpt=None):
         """long_occlude / pingpong=False: the long-stream parity form (tests/test_gpu_long_stream.py) - `n_distinct` frames of
-        the stream with synth.PersonScene's long occlusion windows, played once front to back."""
+        the stream with synth.PersonScene's long occlusion windows, played once front to back.
+        weights / ckpt (SURVEY 8d "Weights"): paths of a real Darknet .weights file / a ckpt.t7; with `weights` the head logits are
+        NOT injected - the detector sees what it sees (bench.py --weights/--ckpt, the un-injected leg)."""
         from .deep_sort import DeepSort, Extractor
         from .models import Darknet
         from . import pipeline as pl
         self.cfg = CONFIGS[config]
         self.batch = B = int(batch)
         self.cfg_text = cfgs.cfg_text(self.cfg["net"], IMG, IMG)
-        self.blob = synth.darknet_weights_blob(self.cfg_text, seed=0)
+        self.injected = weights is None
         self.net = Darknet(None, img_size=(IMG, IMG), batch_max=B, cfg_text=self.cfg_text)
         if half:
             self.net.half()
-        self.net.load_darknet_weights(None, blob=self.blob)
-        self.reid_sd = synth.reid_state_dict(0)
+        if weights is None:
+            self.blob = synth.darknet_weights_blob(self.cfg_text, seed=0)
+            self.net.load_darknet_weights(None, blob=self.blob)
+        else:
+            self.net.load_darknet_weights(weights)
+        self.reid_sd = synth.reid_state_dict(0) if ckpt is None else ckpt                  # (Extractor takes a state dict or a path)
         per_frame = self.cfg["visible"] or self.cfg["persons"]
         self.per_frame = per_frame
         self.ds = DeepSort(Extractor(self.reid_sd, max_crops=B * (per_frame + 8)), use_cuda=True, **DS_PARAMS)
@@ -46,12 +52,13 @@ class Workload:
         n_distinct = n_distinct or max(4 * B, 32)
         self.scene = synth.PersonScene(self.cfg["persons"], seed=seed, n_visible=self.cfg["visible"], long_occlude=long_occlude)
         frames = np.stack([self.scene.frame(t) for t in range(n_distinct)], 0)
-        heads = self.net.yolo_heads()
-        self.inj = [synth.head_injection(self.scene.boxes(t)[1], (self.scene.H, self.scene.W), (IMG, IMG), heads, cls=0)
-                    for t in range(n_distinct)]
         self.order = list(range(n_distinct)) + (list(range(n_distinct - 1, -1, -1)) if pingpong else [])
         self.n_sets = len(self.order) // B
-        pl.load_injection_sets(self.net, [[self.inj[self.order[s * B + b]] for b in range(B)] for s in range(self.n_sets)])
+        if self.injected:
+            heads = self.net.yolo_heads()
+            self.inj = [synth.head_injection(self.scene.boxes(t)[1], (self.scene.H, self.scene.W), (IMG, IMG), heads, cls=0)
+                        for t in range(n_distinct)]
+            pl.load_injection_sets(self.net, [[self.inj[self.order[s * B + b]] for b in range(B)] for s in range(self.n_sets)])
         self.H, self.W = frames.shape[1:3]
         self.frame_bytes = self.H * self.W * 3
         self._pinned = _lib.PinnedArray((len(self.order),) + frames.shape[1:], np.uint8)     # host copy of the stream, in play order,
@@ -75,7 +82,7 @@ class Workload:
         will follow, its frames are announced to the pipeline now (yds_pipeline_prefetch_host)."""
         B = self.batch
         s, s_next = i % self.n_sets, (i + 1) % self.n_sets
-        if self._sel != s:
+        if self.injected and self._sel != s:
             self._pl.select_injection_set(self.net, s)
             self._sel = s
         if host_frames:
@@ -84,11 +91,11 @@ class Workload:
                 self.pipe.prefetch_host(self.ring[s2 * B:(s2 + 1) * B])
             cur = self.ring[s * B:(s + 1) * B]
             nxt = self.ring[s_next * B:(s_next + 1) * B] if prefetch else None
-            out = self.pipe.step_host(cur, nxt, select_next=(s_next if prefetch else None))
+            out = self.pipe.step_host(cur, nxt, select_next=(s_next if prefetch and self.injected else None))
         else:
             dev = self.to_device()
             nxt = dev.offset(s_next * B * self.frame_bytes) if prefetch else None
-            out = self.pipe.step(dev.offset(s * B * self.frame_bytes), self.H, self.W, B, nxt, select_next=(s_next if prefetch else None))
+            out = self.pipe.step(dev.offset(s * B * self.frame_bytes), self.H, self.W, B, nxt, select_next=(s_next if prefetch and self.injected else None))
         if prefetch:
             self._sel = s_next
         return out
