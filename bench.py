@@ -130,7 +130,8 @@ def video_detector_leg(config, B, seed, n_frames, device_overlay=True):
         f.write(cfgs.coco_names_text())
     vd = VideoDetector(wl.net, f.name, thres=CONF_THRES, nms_thres=NMS_THRES, class_mask=CLASS_MASK, tracker=wl.ds, device_overlay=device_overlay)
     os.unlink(f.name)
-    assert vd.batch_frames is None and vd.AUTO_BATCH == B
+    assert vd.batch_frames is None
+    vd.AUTO_BATCH = B                                                 # (the generator's default read-ahead is the bench step of this config)
 
     class InjectingPipeline(pl.Pipeline):                             # bench-only head-logit injection, set i for the i-th batch of the ring
         i, sel = 0, None
@@ -276,8 +277,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 32 frames = 2 s of the pipeline: long enough for external samplers such as rocm-smi to land inside the timed region)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step (detector batch).  32 since round 4: the 19x19 / 38x38 layers have 722 / 2888 wave tiles for 1024 SIMDs at 16 frames "
-                                                            "(parallelism bound), twice that at 32: conv time per frame -7 %%, end to end +2 %%; 16 = rounds 1-3")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step (detector batch).  Default by config (workload.DEFAULT_BATCH): 64 for cfg2 / cfg3 / cfg4 since round 6 - "
+                                                              "the 19x19 layers of a 32-frame batch are 368 window tiles for 256 CUs (1.44 rounds, a quarter of the second "
+                                                              "round idle), 728 at 64 frames: +4 %% end to end on one box (profiles/r06_batch_sweep.txt); 32 for cfg5, whose ReID pass "
+                                                              "of 4800 crops per 32 frames already fills the chip (64: -1.4 %%); 32 = rounds 4-5, 16 = rounds 1-3")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg4 = configs[3]: yolov4 + DeepSORT, one stream per GPU (seeds = rank)")
     ap.add_argument("--seed-base", type=int, default=0, help="stream seed of rank r = seed-base + r")
@@ -322,7 +325,8 @@ def main():
     _lib.init()                    # YDS_DEVICE, else LOCAL_RANK (ordinal 0 when the launcher masks one device per rank)
     lib = _lib.load()
 
-    B, K, W = args.batch, args.steps, args.warmup
+    from yolo_deepsort_amd.workload import DEFAULT_BATCH
+    B, K, W = args.batch or DEFAULT_BATCH[args.config], args.steps, args.warmup
     if args.math == "f32":
         lib.yds_set_conv_math(0)
     wl = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base), half=args.half)
@@ -443,9 +447,15 @@ def main():
         # share the CUs and stretch every detector launch without the chip doing less (config.schedule / schedule_trial say what the
         # product picked on this box and why).
         wl.pipe.set_schedule(0)
-        pl.conv_clock(reset=True)                                 # one-wave clock probe on its own stream beside the diagnostic leg (never beside `value`)
-        variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, base, peak)
-        clock_ghz, clock_ms = pl.conv_clock(reset=False)          # shader clock the chip held over that leg's W + K steps
+        # the driver's sclk sampled on a host thread beside the diagnostic leg (never beside `value`); in-kernel sampling only exists in a
+        # -DYDS_CLOCK_PROBE build (tools/) - the product kernels carry none since round 6
+        pl.conv_clock(reset=True)
+        with pl.SclkSampler() as sclk:
+            variants, dom, allc, dt_ev = measure_roofline(wl, ranks, sync, pl, K, W, base, peak)
+        clock_ghz, clock_ms = pl.conv_clock(reset=False)
+        clock_src = "s_memtime / s_memrealtime inside the window kernels (-DYDS_CLOCK_PROBE build)"
+        if not clock_ghz:
+            clock_ghz, clock_ms, clock_src = sclk.ghz() or 0.0, len(sclk.samples) * sclk.period * 1e3, "driver sclk (sysfs pp_dpm_sclk, %d samples on a host thread beside the diagnostic leg)" % len(sclk.samples)
         wl.pipe.set_schedule(sched_arg)
         if rank == 0 and dom is not None:
             note = ("dense fp16 MFMA 2500 TFLOP/s / 3 MFMAs per fp32-equivalent MAC" if f16x3
@@ -460,9 +470,8 @@ def main():
                 # every convolution of the step (detector + ReID network) against the step's wall time: a floor of the
                 # conv efficiency that charges every non-conv kernel, gap and host stall to the convolutions
                 pipeline_conv_frac=round(flops_frame * K * B / dt / 1e12 / peak, 4),
-                # the peak assumes 2.4 GHz; the chip is power limited under this load: clock sampled by a one-wave probe kernel on
-                # its own stream (s_memtime / s_memrealtime at both ends of this diagnostic leg; csrc/clock_probe.hip)
-                sustained_clock_ghz=round(clock_ghz, 3), nominal_clock_ghz=2.4,
+                # the peak assumes 2.4 GHz; the chip is power limited under this load
+                sustained_clock_ghz=round(clock_ghz, 3) if clock_ghz else None, sustained_clock_source=clock_src, nominal_clock_ghz=2.4,
                 peak_at_sustained_clock=round(dom["peak"] * clock_ghz / 2.4, 1) if clock_ghz else None,
                 frac_at_sustained_clock=round(dom["achieved"] / (dom["peak"] * clock_ghz / 2.4), 4) if clock_ghz else None)
 

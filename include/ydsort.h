@@ -300,12 +300,12 @@ const char *yds_conv_variant_name(int variant);
  * average launch duration in us and the tile variant that was picked. */
 int yds_conv_bench(int n, int h, int w, int cin, int cout, int ksize, int stride, int act, int with_residual,
                    int iters, double *avg_us, int *variant);
-/* Shader clock the chip sustained since the last call with reset != 0: a one-wave probe kernel on its own stream samples
- * s_memtime (shader cycles) and s_memrealtime (100 MHz) when it starts and when this call stops it (it sleeps in between, and
- * ends by itself after 30 s); *ghz = cycles / time, *sampled_ms = the interval.  reset != 0 starts the next interval, reset = 0
- * only reads.  The product kernels carry no sampling code (rounds 3-5 sampled inside the window-resident kernels; that form is
- * kept behind -DYDS_CLOCK_PROBE for tools/ builds).  The dense-MFMA peaks are quoted at 2.4 GHz; under this load the chip is
- * power limited well below that, which bench.py reports next to the nominal roofline fraction. */
+/* Shader clock sampled INSIDE the window-resident conv kernels since the last reset (one workgroup in 32 reads s_memtime and
+ * s_memrealtime at its start and end; *ghz = cycles / time over the samples, *sampled_ms = the workgroup time sampled) - ONLY in a
+ * library built with -DYDS_CLOCK_PROBE (tools/ builds; YDS_BUILD_TAG / YDS_EXTRA_FLAGS of yolo_deepsort_amd/build.py).  The product
+ * kernels carry no sampling code since round 6: this entry then returns *ghz = *sampled_ms = 0, and bench.py reports the driver's own
+ * sclk (sysfs pp_dpm_sclk of the bound device, sampled beside its diagnostic leg) as roofline.sustained_clock_ghz.  The dense-MFMA
+ * peaks are quoted at 2.4 GHz; under this load the chip is power limited well below that. */
 int yds_conv_clock(double *ghz, double *sampled_ms, int reset);
 /* parity-test entry: one convolution through a chosen kernel variant (formats as the planner would pick them for the
  * current conv math).  x NHWC [n,h,w,cin], w [cout][kh][kw][cin] (BN already folded), res NHWC or NULL

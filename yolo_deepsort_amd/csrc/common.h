@@ -42,10 +42,6 @@ hipStream_t make_stream(bool latency_role);   // non-blocking stream; optional C
         return nullptr;                                                                        \
     }
 
-// ---- sustained shader clock beside a running workload (clock_probe.hip): one wave on its own stream ---------------
-void clock_probe_start(double max_seconds);
-void clock_probe_stop(double *ghz, double *ms);          // zeros when no probe was running
-
 // ---- device buffer ------------------------------------------------------------------------
 template <typename T> struct DevBuf {
     T *p = nullptr;

@@ -163,14 +163,14 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[0][0][e] = (HALF ? acc1[0][0][e] : acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
-        // the staging area (32 x 68 floats) lives in the input patch, which phase A is done with
-        conv_epilogue_rows<BM, BN, WM, WN, ACT, RES_AFTER_ACT, 1, 1, NT, PatchRows>(p3, acc1, reinterpret_cast<float *>(xp),
-                                                                                     PatchRows{img, oy0, ox0, H, W}, 0, tid);
+        // whole-tile staging (128 x 68 floats) in the input patch, which phase A is done with: one barrier pair, not four passes (round 6)
+        conv_epilogue_rows<BM, BN, WM, WN, ACT, RES_AFTER_ACT, 1, 1, NT, PatchRows, true>(p3, acc1, reinterpret_cast<float *>(xp),
+                                                                                           PatchRows{img, oy0, ox0, H, W}, 0, tid);
     }
 }
 
 template <int ACT, bool HALF> void launch_inst(const ConvKernelArgs &k2, const ConvKernelArgs &k3, hipStream_t s) {
-    static_assert((BM / WM) * (BN + 4) * 4 <= XP_BYTES, "epilogue staging must fit the input patch");
+    static_assert(BM * (BN + 4) * 4 <= XP_BYTES, "whole-tile epilogue staging must fit the input patch");
     const int n_img = k2.M / (k2.H * k2.W);
     const int tiles_y = (k2.H + TH - 1) / TH, tiles_x = (k2.W + TW - 1) / TW, n_tiles = n_img * tiles_y * tiles_x;
     static bool attr_set = false;

@@ -199,14 +199,16 @@ __global__ __launch_bounds__(NT, 1) void conv_stem2_f16x3(ConvKernelArgs p0, Con
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[0][0][e] = (HALF ? acc1[0][0][e] : acc1[0][0][e] + acc2[0][0][e] * (1.f / LO_SCALE)) * (1.f / A_SCALE);
-        // the staging area (32 x 68 floats) lives in the RGB tile, which phase A is done with
-        conv_epilogue_rows<BM, BN, WM, WN, ACT1, RES_NONE, 1, 1, NT, StemRows>(p1, acc1, reinterpret_cast<float *>(rgb),
-                                                                                 StemRows{img, oy0, ox0, p1.Ho, p1.Wo}, 0, tid);
+        // whole-tile staging (128 x 68 floats) in the layer-0 patch once every wave is done reading it: one barrier pair instead of
+        // the four passes of 32 rows that the RGB tile could hold (round 6)
+        __syncthreads();
+        conv_epilogue_rows<BM, BN, WM, WN, ACT1, RES_NONE, 1, 1, NT, StemRows, true>(p1, acc1, reinterpret_cast<float *>(patch),
+                                                                                       StemRows{img, oy0, ox0, p1.Ho, p1.Wo}, 0, tid);
     }
 }
 
 template <int ACT0, int ACT1, bool HALF> void launch_inst(const ConvKernelArgs &k0, const ConvKernelArgs &k1, hipStream_t s) {
-    static_assert((BM / WM) * (BN + 4) * 4 <= RGB_BYTES, "epilogue staging must fit the RGB tile");
+    static_assert(BM * (BN + 4) * 4 <= PATCH_BYTES, "whole-tile epilogue staging must fit the layer-0 patch");
     const int n_img = k0.M / (k0.H * k0.W);
     const int tiles_y = (k1.Ho + TH - 1) / TH, tiles_x = (k1.Wo + TW - 1) / TW, n_tiles = n_img * tiles_y * tiles_x;
     static bool attr_set = false;

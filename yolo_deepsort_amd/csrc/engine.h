@@ -238,6 +238,8 @@ struct TrackerIface {
     virtual void step_batch(int n, const float *tlwh_host, const int *first, const float *feats_dev, const float *payload_host, const char *skip,
                             int32_t *out6_host, int cap, int32_t *counts) = 0;
     virtual int num_tracks() const = 0;
+    // the next step / step_batch starts behind `ev` on the tracker's own stream (features produced on another stream: no host wait)
+    virtual void wait_for(hipEvent_t ev) = 0;
 };
 
 }  // namespace yds

@@ -368,7 +368,11 @@ public:
         last_serial = serial;
         auto t_nms = clk::now();
         const int D_all = (int)cur.payload.size();
-        if (D_all) YDS_HIP(hipEventSynchronize(ev_feat));
+        // One frame per step (the frame-by-frame API): the association is ordered behind the features ON THE DEVICE - its stream waits
+        // for the event - instead of by a host wake-up between the two (round 6: one round trip less on the latency path; stage_us[3]
+        // then holds the enqueue only and stage_us[4] the ReID pass + association).  Batches keep the host wait: it is what lets the
+        // host start the next batch's work in the right order below.
+        if (D_all) { if (batch == 1 && !next_frames_dev) trk->wait_for(ev_feat); else YDS_HIP(hipEventSynchronize(ev_feat)); }
         auto t_reid = clk::now();
         // Crowded scenes (the association of a batch takes long and is all small latency-bound kernels and host syncs):
         // before associating, finish the next batch's detector + NMS and start its ReID pass, so that the matrix

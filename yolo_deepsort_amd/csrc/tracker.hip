@@ -584,6 +584,7 @@ public:
         return count;
     }
     // frames of one batch, in order, one synchronisation (the pipeline's association stage); skip[b]: tracker not called
+    void wait_for(hipEvent_t ev) override { YDS_HIP(hipStreamWaitEvent(stream, ev, 0)); }
     void step_batch(int n, const float *tlwh_host, const int *first, const float *feats_dev, const float *payload, const char *skip, int32_t *out6,
                     int cap, int32_t *counts) override {
         std::vector<FrameIn> fr;

@@ -232,7 +232,7 @@ class VideoDetector:
         self.image_detector = ImageDetector(model, class_path, thickness=thickness, thres=thres, nms_thres=nms_thres,
                                             win_size=win_size, overlap=overlap, half=half)
 
-    AUTO_BATCH = 32          # frames per step of the batched path when batch_frames is left to the source (bench.py's step size)
+    AUTO_BATCH = 64          # frames per step of the batched path when batch_frames is left to the source (bench.py's step size for cfg2 / cfg3; the reference reads 128 ahead)
 
     @staticmethod
     def _is_live(video_path):

@@ -104,10 +104,54 @@ def conv_timing(net, mode=0):
 
 
 def conv_clock(reset=True):
-    """(GHz, sampled ms): the shader clock sustained inside the window-resident conv kernels since the last reset."""
+    """(GHz, sampled ms) of the in-kernel clock sampling of a -DYDS_CLOCK_PROBE build since the last reset; (0, 0) from the product
+    library, whose kernels carry no sampling code (bench.py then reads the driver's sclk instead: SclkSampler)."""
     ghz, ms = C.c_double(0), C.c_double(0)
     _lib.check(_lib.load().yds_conv_clock(C.byref(ghz), C.byref(ms), 1 if reset else 0))
     return ghz.value, ms.value
+
+
+class SclkSampler:
+    """Samples the driver's shader clock of the bound device (sysfs /sys/bus/pci/devices/<bdf>/pp_dpm_sclk: the line marked '*') on a
+    host thread while a workload runs: `with SclkSampler() as s: ...; s.ghz()`.  None when the file is absent or unreadable."""
+
+    def __init__(self, period_s=0.01):
+        import threading
+        self.period, self.samples, self._stop = period_s, [], threading.Event()
+        bdf = _lib.pci_bus_id()
+        self.path = "/sys/bus/pci/devices/%s/pp_dpm_sclk" % bdf.lower() if bdf else None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            with open(self.path) as f:
+                for line in f:
+                    if line.rstrip().endswith("*"):
+                        return float(line.split(":")[1].lower().split("mhz")[0])
+        except Exception:                                   # noqa: BLE001 - no sysfs in this container, another driver version ...
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            v = self._read()
+            if v is not None:
+                self.samples.append(v)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.path:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(timeout=1)
+
+    def ghz(self):
+        busy = [v for v in self.samples if v > 300]          # (drop the idle / sleep state between legs)
+        return round(sum(busy) / len(busy) / 1e3, 3) if busy else None
 
 
 def load_injection_sets(net, sets, logit=6.0):

@@ -18,6 +18,7 @@ CONFIGS = {
     "cfg4": dict(net="yolov4", persons=30, visible=None, workload="yolov4.cfg 608x608 + DeepSORT, independent synthetic 1080p streams (seed = rank), one per GPU, result rows all-gathered after every step (transport: `exchange`)"),
     "cfg5": dict(net="yolov4", persons=200, visible=150, workload="yolov4.cfg 608x608 + DeepSORT, crowd stream 200 tracks / 150 detections per frame"),
 }
+DEFAULT_BATCH = {"cfg2": 64, "cfg3": 64, "cfg4": 64, "cfg5": 32}        # frames per step of bench.py (profiles/r06_batch_sweep.txt)
 DS_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)   # video_deepsort.py:18-25
 IMG = 608
 CONF_THRES, NMS_THRES, CLASS_MASK = 0.5, 0.4, [0, 2, 4]
