@@ -252,7 +252,7 @@ def committed_traffic(config, kernel, B, mode=""):
     counters cannot be read from inside this process."""
     cfg_key = "cfg3" if config == "cfg4" else config
     out = None
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{cfg_key}{mode}.json")
         if os.path.exists(tpath) and json.load(open(tpath)).get("frames_per_step", 16) == B:
             rec = json.load(open(tpath))["kernels"].get(kernel)
@@ -261,7 +261,7 @@ def committed_traffic(config, kernel, B, mode=""):
                            traffic_unit="bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, profiles/" + os.path.basename(tpath) + ")")
                 break
     # matrix-pipe utilisation of the same kernel from the committed SQ_VALU_MFMA_BUSY_CYCLES pass (tools/profile_bench.sh MFMA=1)
-    for rnd in ("r05",):
+    for rnd in ("r06", "r05"):
         mpath = os.path.join(ROOT, "profiles", f"{rnd}_mfma_busy_{cfg_key}{mode}.json")
         if os.path.exists(mpath):
             rec = json.load(open(mpath))["kernels"].get(kernel)
@@ -277,9 +277,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 32 frames = 2 s of the pipeline: long enough for external samplers such as rocm-smi to land inside the timed region)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=None, help="frames per step (detector batch).  Default by config (workload.DEFAULT_BATCH): 64 for cfg2 / cfg3 / cfg4 since round 6 - "
+    ap.add_argument("--batch", type=int, default=None, help="frames per step (detector batch).  Default by config (workload.DEFAULT_BATCH): 68 for cfg2 / cfg3 / cfg4 since round 6 - "
                                                               "the 19x19 layers of a 32-frame batch are 368 window tiles for 256 CUs (1.44 rounds, a quarter of the second "
-                                                              "round idle), 728 at 64 frames: +4 %% end to end on one box (profiles/r06_batch_sweep.txt); 32 for cfg5, whose ReID pass "
+                                                              "round idle), 768 = 3.0 rounds at 68 frames: +4..5 %% end to end (profiles/r06_batch_sweep.txt); 32 for cfg5, whose ReID pass "
                                                               "of 4800 crops per 32 frames already fills the chip (64: -1.4 %%); 32 = rounds 4-5, 16 = rounds 1-3")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg4 = configs[3]: yolov4 + DeepSORT, one stream per GPU (seeds = rank)")

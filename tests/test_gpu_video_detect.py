@@ -235,15 +235,18 @@ def test_default_batching_and_device_output_stage_vs_reference_generator(tmp_pat
     assert not VideoDetectorAuto()._is_live("clip.mp4") and not VideoDetectorAuto()._is_live(iter(()))
     images = {}
     for device_overlay in (True, False):
-        c, sc, net, frames, inj, tracker, act, VideoDetector, cfgs = _build(case, 32)
+        c, sc, net, frames, inj, tracker, act, VideoDetector, cfgs = _build(case, 16)      # (grown by the generator to the batch it picks)
         vd = VideoDetector(net, _names(tmp_path, cfgs), thres=sc["thres"], nms_thres=sc["nms_thres"], skip_frames=c["skip_frames"],
                            class_mask=c["class_mask"], tracker=tracker, action_id=act, device_overlay=device_overlay)
         assert vd.batch_frames is None
         index = {_key(f): t for t, f in enumerate(frames)}
-        vd._batch_now = vd.AUTO_BATCH
+        # the default read-ahead: AUTO_BATCH frames, or the whole clip when that is shorter (the source can tell its length)
+        B = min(vd.AUTO_BATCH, len(frames))
+        assert vd._source_len(Capture(frames[..., ::-1], sc["fps"])) == len(frames)
+        vd._batch_now = B
         groups = [[index[_key(f)] for f, proc in grp if proc]
                   for grp in vd._processed_batches(Capture(frames[..., ::-1], sc["fps"]), c["skip_secs"])]
-        B = vd.AUTO_BATCH
+        net.set_batch_max(B)
         empty = np.zeros((0, 9), F32)
         pl.load_injection_sets(net, [[inj[t] for t in grp] + [empty] * (B - len(grp)) for grp in groups])
 
@@ -259,7 +262,7 @@ def test_default_batching_and_device_output_stage_vs_reference_generator(tmp_pat
                 return out
         vd._pipe = InjectingPipeline(net, tracker, vd.image_detector.thres, vd.image_detector.nms_thres, class_mask=c["class_mask"])
         yields = list(vd.detect(Capture(frames[..., ::-1], sc["fps"]), skip_secs=c["skip_secs"], show_fps=False))
-        assert vd._pipe.i == len(groups) and vd._batch_now == 32 and vd.host_us["frames"] == len(yields)
+        assert vd._pipe.i == len(groups) and vd._batch_now == B and vd.host_us["frames"] == len(yields)
         _compare(case, c, g, yields)
         images[device_overlay] = [y[0] for y in yields]
     assert len(images[True]) == len(images[False]) > 0

@@ -9,6 +9,7 @@ math=${MATH:-f16x3}; sfx=""; [ "$math" = "f32" ] && sfx="_f32"
 half=""; [ "${HALF:-0}" = "1" ] && { half="--half"; sfx="_half"; }      # Darknet.half(): the 2-byte activation mode
 steps=${STEPS:-20}; [ "$math" = "f32" ] && steps=${STEPS:-8}
 export YDS_TUNE_CACHE=/tmp/yds_tune_$cfg$sfx.txt
+export YDS_PROFILE_BATCH=$(python -c "from yolo_deepsort_amd.workload import DEFAULT_BATCH; print(DEFAULT_BATCH['$cfg'])")   # frames per step the passes run at (recorded in traffic_*.json)
 common="--config $cfg --math $math $half --no-extras --cpu-frames 0 --latency-steps 0 --schedule ${SCHED:-serialized}"
 python bench.py $common --steps 5 --warmup 2 > $out/bench_${cfg}${sfx}_plain.json 2>$out/err1.log
 cd /tmp

@@ -137,6 +137,7 @@ public:
     void launch_detector_head(const uint8_t *frames_dev, int h, int w, int batch, int slot, bool split) {
         const int k = slot >= 0 ? slot : (in_flight_slot ^= 1);
         head_slot = k;
+        reid_in_pass[k] = false;                                    // (a head re-recorded for this slot: no ReID interval of an earlier pass belongs to it)
         for (int b = 0; b < NSTAGE; ++b)                            // frames uploaded by step_host: wait for the copy engine
             if (stage[b].p && frames_dev == stage[b].p && hipEventQuery(up_done[b]) != hipSuccess)
                 YDS_HIP(hipStreamWaitEvent(net->stream, up_done[b], 0));   // (only while the copy is still running: see step())

@@ -232,7 +232,8 @@ class VideoDetector:
         self.image_detector = ImageDetector(model, class_path, thickness=thickness, thres=thres, nms_thres=nms_thres,
                                             win_size=win_size, overlap=overlap, half=half)
 
-    AUTO_BATCH = 64          # frames per step of the batched path when batch_frames is left to the source (bench.py's step size for cfg2 / cfg3; the reference reads 128 ahead)
+    AUTO_BATCH = 68          # frames per step of the batched path when batch_frames is left to the source: bench.py's step size for the 608 x 608 nets
+    #                          (workload.DEFAULT_BATCH says why 68; the reference itself reads 128 frames ahead); a shorter clip is read whole
 
     @staticmethod
     def _is_live(video_path):
@@ -575,9 +576,26 @@ class VideoDetector:
             if real_show and cv2 is not None:
                 cv2.destroyAllWindows()
 
+    @staticmethod
+    def _source_len(video_path):
+        """Frames the source holds, when it can tell without being consumed (a sequence, an .npy file, an open capture); else None."""
+        try:
+            if hasattr(video_path, "isOpened"):
+                n = int(video_path.get(7))                           # cv2.CAP_PROP_FRAME_COUNT
+                return n if n > 0 else None
+            if isinstance(video_path, str):
+                return int(np.load(video_path, mmap_mode="r").shape[0]) if video_path.endswith(".npy") else None
+            return len(video_path) if hasattr(video_path, "__len__") else None
+        except Exception:                                             # noqa: BLE001 - a source that cannot tell simply gets the default
+            return None
+
     def _detect_impl(self, video_path, show_fps=True, skip_secs=0):
         # (the tracker-side NMS option reorders detections on the host, so it keeps the frame-by-frame path)
         bf = self.batch_frames if self.batch_frames is not None else (1 if self._is_live(video_path) else self.AUTO_BATCH)
+        if self.batch_frames is None and bf > 1:
+            n = self._source_len(video_path)                          # a clip shorter than the default read-ahead: no buffers for frames
+            if n is not None:                                         # that will never come (every capacity follows the batch size)
+                bf = max(1, min(bf, n))
         if bf > 1 and self._batchable():
             yield from self._detect_batched(video_path, show_fps, skip_secs, bf)
             return

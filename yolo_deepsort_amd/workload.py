@@ -18,7 +18,11 @@ CONFIGS = {
     "cfg4": dict(net="yolov4", persons=30, visible=None, workload="yolov4.cfg 608x608 + DeepSORT, independent synthetic 1080p streams (seed = rank), one per GPU, result rows all-gathered after every step (transport: `exchange`)"),
     "cfg5": dict(net="yolov4", persons=200, visible=150, workload="yolov4.cfg 608x608 + DeepSORT, crowd stream 200 tracks / 150 detections per frame"),
 }
-DEFAULT_BATCH = {"cfg2": 64, "cfg3": 64, "cfg4": 64, "cfg5": 32}        # frames per step of bench.py (profiles/r06_batch_sweep.txt)
+# frames per step of bench.py (profiles/r06_batch_sweep.txt).  68 for the 608 x 608 detectors: one workgroup per CU and 256-pixel tiles make a
+# layer's time a step function of its tile count, and 68 x 361 = 24 548 pixels of a 19 x 19 map are 95.9 -> 96 tiles of 256: x 8 filter tiles
+# = 768 = exactly 3 rounds on 256 CUs (38 x 38: 384 x 4 = 6.0 rounds, 76 x 76: 1535 x 2 = 11.99) - at 64 frames they are 2.84 / 5.64 / 11.3,
+# at 32 (rounds 4-5) 1.44 / 2.83 / 5.64.  cfg5's 4800-crop ReID pass fills the chip at 32 frames already (64: -1.4 %, 34: equal).
+DEFAULT_BATCH = {"cfg2": 68, "cfg3": 68, "cfg4": 68, "cfg5": 32}
 DS_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)   # video_deepsort.py:18-25
 IMG = 608
 CONF_THRES, NMS_THRES, CLASS_MASK = 0.5, 0.4, [0, 2, 4]
