@@ -269,6 +269,7 @@ def committed_traffic(config, kernel, B, mode=""):
                 out = dict(out or {}, mfma_busy=rec["mfma_busy"],
                            mfma_busy_note="SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x shader cycles of the launch), rocprofv3 --pmc pass over this "
                                           "command, profiles/" + os.path.basename(mpath))
+                break
     return out
 
 
@@ -620,8 +621,8 @@ def main():
                        **({} if solo is None else {"rank0_single": solo,
                                                    "efficiency_vs_rank0_single": round(frames_total / dt / (world * solo["value"]), 4)}),
                        "schedule_trial": None if trial is None else dict(
-                           note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds per 6 measured steps under either "
-                                "schedule on this box, per rank; `schedule` is what the timed steps then ran under",
+                           note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds of three measured steps (the better of two groups, timed "
+                                "inside the step call) under either schedule on this box, per rank; `schedule` is what the timed steps then ran under",
                            per_rank=trial, with_upload=trial_up, set_up_steps=n_set),
                        **ranks.describe()},
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_with_upload is the PCIe-inclusive rate",

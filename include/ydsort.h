@@ -243,7 +243,8 @@ int yds_pipeline_prefetch_host(yds_pipe *, const uint8_t *frames_host, int h, in
  * yds_pipeline_step_host; two streams for smaller passes; env YDS_PIPE_SERIAL overrides; pipeline.cpp `Trial`).
  * yds_pipeline_last_schedule: 1 if the last step ran serialized, else 0.
  * yds_pipeline_schedule_trial: what the trial of an entry (uploaded = 0: yds_pipeline_step, 1: yds_pipeline_step_host) measured -
- * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds per 6 measured steps under either schedule. */
+ * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds the three measured steps of the BETTER of a schedule's two
+ * groups spent inside the step call (round 6; rounds 4-5: wall time between returns, both groups summed). */
 int yds_pipeline_set_schedule(yds_pipe *, int min_crops);
 /* Byte order of the frames handed to yds_pipeline_step / _step_host: 0 = R, G, B (default: what video_detect.py:33-36 makes of a
  * decoded frame before the detector sees it), 1 = B, G, R as a decoder delivers them - the resize front end and the ReID crops then

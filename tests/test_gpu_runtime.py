@@ -91,6 +91,11 @@ def test_two_rank_bench_path_on_one_gpu(tmp_path):
     c = line["config"]
     assert c["transport"] == "gloo" and c["requested"] == "gloo" and c["rccl_world"] == 0 and c["rccl_version"] is None
     assert len(c["rank_values"]) == 2 and all(v > 0 for v in c["rank_values"]) and c["exchange_block_rows"] >= 64
+    # the N > 1 line explains itself (VERDICT r5 'next' #8): every rank's own ms per step, rank 0 alone before the communicator formed
+    # (on a workload of its own: the streams' rows below still equal fresh single-rank runs), and the ratio the two give
+    assert len(c["rank_ms_per_step"]) == 2 and all(v > 0 for v in c["rank_ms_per_step"])
+    assert c["rank0_single"]["value"] > 0 and c["rank0_single"]["steps"] >= 2
+    assert abs(c["efficiency_vs_rank0_single"] - line["value"] / (2 * c["rank0_single"]["value"])) < 1e-3
     g = np.load(both)
     total = 0
     for seed in (0, 1):

@@ -740,3 +740,35 @@ def test_batched_path_is_gated_on_the_package_tracker_and_live_captures():
     v = vd(ds)
     v.image_detector.win_size = (416, 416)                                                 # tiled detection: frame by frame
     assert not v._batchable()
+
+
+def test_auto_batch_follows_the_clip_length_and_sclk_parsing(tmp_path):
+    """Round 6: the default read-ahead never exceeds what the source holds (a 6-frame clip must not size every buffer for 68 frames),
+    and the roofline record's clock reader parses the driver's pp_dpm_sclk lines."""
+    from yolo_deepsort_amd.detect import VideoDetector
+    from yolo_deepsort_amd import pipeline as pl
+
+    class Cap:
+        def __init__(self, n):
+            self.n = n
+
+        def isOpened(self):
+            return True
+
+        def get(self, prop):
+            return float(self.n)
+
+    assert VideoDetector._source_len(Cap(6)) == 6 and VideoDetector._source_len(Cap(0)) is None
+    assert VideoDetector._source_len([1, 2, 3]) == 3 and VideoDetector._source_len(iter(())) is None
+    np.save(tmp_path / "clip.npy", np.zeros((5, 4, 4, 3), np.uint8))
+    assert VideoDetector._source_len(str(tmp_path / "clip.npy")) == 5 and VideoDetector._source_len("movie.mp4") is None
+    s = object.__new__(pl.SclkSampler)
+    s.path = str(tmp_path / "pp_dpm_sclk")
+    (tmp_path / "pp_dpm_sclk").write_text("0: 500Mhz\n1: 1950Mhz *\n2: 2400Mhz\n")
+    assert s._read() == 1950.0
+    (tmp_path / "pp_dpm_sclk").write_text("S: 109Mhz *\n0: 500Mhz\n1: 2400Mhz\n")
+    assert s._read() == 109.0
+    s.samples, s.period = [109.0, 1950.0, 2050.0], 0.01
+    assert s.ghz() == 2.0                                   # the sleep state between legs is not a sample of the loaded clock
+    s.path = str(tmp_path / "absent")
+    assert s._read() is None

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
     }
     float bias2[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bias2[e] = p2.bias[(e & 3) + 8 * (e >> 2) + 4 * kb];
+    for (int e = 0; e < 16; ++e) bias2[e] = p2.bias[(e & 3) + 8 * (e >> 2) + 4 * kb] * A_SCALE;      // in the accumulators' scaled domain (exact: a power of two)
     // phase-B fragment bookkeeping
     const int r = wm * 32 + (lane & 31), py = r / TW, px = r - py * TW;
     const int brow = wn * 32 + (lane & 31);
@@ -116,25 +116,33 @@ __global__ __launch_bounds__(NT, 1) void conv_block1_f16x3(ConvKernelArgs p2, Co
             const int ry = pr / PC, rc = pr - ry * PC;
             const bool inside = (unsigned)(oy0 - 1 + ry) < (unsigned)H && (unsigned)(ox0 - 1 + rc) < (unsigned)W;
             const int sw = (pr >> 1) & 7;
+            // (round 6, as in conv_stem2.hip: bias and LeakyReLU in the scaled domain, encoded from there; pixels outside the image - the
+            //  3x3 zero-pads h - take a branch of their own instead of a select per value)
+            if (pix < PPIX) {
+                if (inside) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int e = g * 4 + c;
-                    const float o = (HALF ? c1[e] : c1[e] + c2[e] * (1.f / LO_SCALE)) * (1.f / A_SCALE) + bias2[e];
-                    v[c] = inside ? apply_act<ACT>(o) : 0.f;      // the 3x3 zero-pads h
-                }
-                h16x4 hi, lo;
-                if (HALF) {
+                        for (int c = 0; c < 4; ++c) {
+                            const int e = g * 4 + c;
+                            const float os = (HALF ? c1[e] : c1[e] + c2[e] * (1.f / LO_SCALE)) + bias2[e];
+                            v[c] = ACT == ACT_LEAKY ? fmaxf(os, os * 0.1f) : apply_act<ACT>(os * (1.f / A_SCALE)) * A_SCALE;
+                        }
+                        h16x4 hi, lo;
+                        if (HALF) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) hi[c] = (_Float16)(v[c] * A_SCALE);
+                            for (int c = 0; c < 4; ++c) hi[c] = (_Float16)v[c];
+                        } else {
+                            h16_encode4_scaled(v, hi, lo);
+                        }
+                        *reinterpret_cast<h16x4 *>(hp + pr * 128 + ((g ^ sw) << 4) + kb * 8) = hi;
+                        if (!HALF) *reinterpret_cast<h16x4 *>(hp + pr * 128 + (((4 + g) ^ sw) << 4) + kb * 8) = lo;
+                    }
                 } else {
-                    h16_encode4(v, hi, lo);
-                }
-                if (pix < PPIX) {
-                    *reinterpret_cast<h16x4 *>(hp + pr * 128 + ((g ^ sw) << 4) + kb * 8) = hi;
-                    if (!HALF) *reinterpret_cast<h16x4 *>(hp + pr * 128 + (((4 + g) ^ sw) << 4) + kb * 8) = lo;
+                    const h16x4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                    for (int g = 0; g < (HALF ? 4 : 8); ++g) *reinterpret_cast<h16x4 *>(hp + pr * 128 + ((g ^ sw) << 4) + kb * 8) = z;
                 }
             }
         }

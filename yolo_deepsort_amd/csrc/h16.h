@@ -42,6 +42,17 @@ __device__ __forceinline__ void h16_encode4(const float v[4], h16x4 &hi, h16x4 &
     }
 }
 
+// the same for values that are ALREADY in the scaled domain (xs = x * 2^-8): producers whose accumulators come out scaled and whose
+// activation is positively homogeneous (LeakyReLU, ReLU, linear) skip the unscale / rescale pair
+__device__ __forceinline__ void h16_encode4_scaled(const float xs[4], h16x4 &hi, h16x4 &lo) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        _Float16 h = (_Float16)xs[c];
+        hi[c] = h;
+        lo[c] = (_Float16)((xs[c] - (float)h) * H16_LO_SCALE);
+    }
+}
+
 __device__ __forceinline__ void h16_decode4(const h16x4 &hi, const h16x4 &lo, float v[4]) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] = ((float)hi[c] + (float)lo[c] * (1.f / H16_LO_SCALE)) * (1.f / H16_A_SCALE);

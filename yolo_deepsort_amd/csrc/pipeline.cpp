@@ -251,14 +251,14 @@ public:
     // Which schedule is faster is a property of the box (round 4: serialized +1.2 % on one, two-stream +1.3-3.1 % on four others),
     // so the pipeline times both on the caller's own steps, like conv_autotune times tile variants: steady-state steps (a next
     // batch handed over, >= 256 crops) run in groups of 1 + TRIAL_STEPS - serialized, two-stream, serialized, two-stream; the first
-    // step of a group absorbs the transition - the wall time per group is taken between the returns of step(), and the schedule
-    // with the smaller sum is kept (16 steps in all).
+    // step of a group absorbs the transition - the time the three measured steps spend INSIDE step() is summed per group, and the schedule
+    // whose better group is smaller is kept (16 steps in all; round 6: see trial_step_done).
     // Results do not depend on the schedule (parity tests run both), so the trial is invisible to the caller.  One decision per
     // entry (frames resident in HBM / uploaded inside the step): their balance differs.
     static constexpr int TRIAL_STEPS = 3, TRIAL_GROUPS = 4;      // groups alternate serialized / two-stream: S T S T
     struct Trial {
         int n = 0;                      // steady-state steps seen
-        double t0 = 0, t_serial = 0, t_two = 0;
+        double t0 = 0, t_serial = 0, t_two = 0;   // t0: seconds of the running group; t_*: the better group of each schedule (3 measured steps)
         int decided = 0;                // 0 = measuring, 1 = serialized, -1 = two-stream
     };
     // Schedule of the NEXT ReID pass for an entry while its trial runs.  A group = one transition step + TRIAL_STEPS measured steps;
@@ -266,13 +266,18 @@ public:
     // the clock / temperature drift of the first second under load (the first group ran 7 % faster than steady state on one box)
     // does not decide the comparison.
     bool trial_wants_serial(const Trial &t) const { return t.decided ? t.decided > 0 : (t.n / (TRIAL_STEPS + 1)) % 2 == 0; }
-    void trial_step_done(Trial &t) {
-        using clk = std::chrono::steady_clock;
+    // step_seconds: the time THIS call of step() took (round 6: not the wall time between returns, which charged the caller's own
+    // time between steps - a slow decoder, a consumer rendering - to whichever schedule happened to be on trial); per schedule the
+    // BETTER of its two groups counts (one hiccup inside a three-step group no longer fixes the decision).
+    void trial_step_done(Trial &t, double step_seconds) {
         if (t.decided) return;
-        const double now = std::chrono::duration<double>(clk::now().time_since_epoch()).count();
         const int group = t.n / (TRIAL_STEPS + 1), k = t.n % (TRIAL_STEPS + 1);
-        if (k == 0) t.t0 = now;                                   // the group's transition step has returned
-        if (k == TRIAL_STEPS) (group % 2 == 0 ? t.t_serial : t.t_two) += now - t.t0;
+        if (k == 0) t.t0 = 0;                                     // the group's transition step: not measured
+        else t.t0 += step_seconds;
+        if (k == TRIAL_STEPS) {
+            double &best = group % 2 == 0 ? t.t_serial : t.t_two;
+            best = best > 0 ? std::min(best, t.t0) : t.t0;
+        }
         ++t.n;
         if (t.n == TRIAL_GROUPS * (TRIAL_STEPS + 1)) t.decided = t.t_serial <= t.t_two ? 1 : -1;
     }
@@ -391,7 +396,7 @@ public:
         auto t_end = clk::now();
         stage_us[2] = us(t_begin, t_nms); stage_us[3] = us(t_nms, t_reid); stage_us[4] = us(t_reid, t_end);
         // a steady-state step of a chip-filling ReID pass counts towards the schedule trial of its entry
-        if (!forced && next_frames_dev && D_all >= 256) trial_step_done(trial);
+        if (!forced && next_frames_dev && D_all >= 256) trial_step_done(trial, std::chrono::duration<double>(t_end - t_begin).count());
     }
 
     Darknet *net;
