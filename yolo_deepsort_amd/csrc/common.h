@@ -97,9 +97,13 @@ struct ConvArgs {
     // [n_split, y.c) are written to y2 (same pixels, own stride / channel offset); w / w16 / bias hold both filter sets
     View y2;
     int n_split = 0;
+    // order of the tiles inside an XCD's rectangle (conv_common.h tile_of_block): filter tiles walked together; 0 = one.  Placement only:
+    // results do not depend on it.  launch_conv takes it from bits 8.. of its `variant` argument (what conv_autotune returns).
+    int tile_gn = 0;
 };
 // returns the tile-variant id that was launched (see conv_variant_name)
-int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice
+int launch_conv(const ConvArgs &a, hipStream_t s, int variant = -1);   // variant < 0: built-in default choice; bits 8..: tile order (conv_autotune's packed result); returns the plain id
+constexpr int kVariantMask = 0xff, kTileGnShift = 8;
 int conv_default_variant(const ConvArgs &a);
 bool conv_presplit_input(const ConvArgs &a);   // H16, or F16 in half mode: what the LDS-DMA / window kernels fetch as opaque chunks
 // 3x3 RGB stem + MaxPool2d(3, 2, 1) in one kernel (ReID); a.y is the pooled view.  Returns false when the layer does not qualify.

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "h16.h"
 
+#include <algorithm>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -36,6 +37,8 @@ struct ConvKernelArgs {
     int ldy2 = 0, n_split = 0;
     // XCD-aware tile map: the 8 XCDs own an xm x xn grid of rectangles of rm x rn tiles (workgroup id % 8 = XCD)
     int tiles_m, tiles_n, xm, rm, rn;
+    int gn = 1;                           // filter tiles walked together inside an XCD's rectangle (tile_of_block); set by plan_tile_map
+    int gn_req = 0;                       // ... as requested by the caller (ConvArgs::tile_gn: 0 / 1 = column by column)
 };
 
 constexpr int KALIGN = 32;                // weight rows are zero padded to a multiple of this
@@ -62,10 +65,23 @@ template <int ACT> __device__ __forceinline__ float apply_act(float v) {
 // Workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 and every XCD has a private 4 MiB L2,
 // so each XCD gets a compact rm x rn rectangle of tiles (small A-rows + B-columns footprint per K step) instead
 // of a stripe through the whole problem.  Placement only affects speed, never results.
+// Order INSIDE an XCD's rectangle (round 6): the ~32 workgroups an XCD runs at a time are consecutive ids.  gn = 1 walks the
+// rectangle column by column (32 different pixel tiles against ONE filter tile at a time); gn > 1 walks it in groups of gn filter
+// tiles, filter tile fastest, so that the gn workgroups of one pixel tile run together and share its input window through the L2.
 __device__ __forceinline__ bool tile_of_block(const ConvKernelArgs &p, int &tm, int &tn) {
     const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
-    tm = (xcd % p.xm) * p.rm + idx % p.rm;
-    tn = (xcd / p.xm) * p.rn + idx / p.rm;
+    int lm, ln;
+    if (p.gn <= 1) {
+        lm = idx % p.rm;
+        ln = idx / p.rm;
+    } else {
+        const int per = p.rm * p.gn, grp = idx / per, w = idx - grp * per;
+        const int g = min(p.gn, p.rn - grp * p.gn);              // the last group of columns may be narrower
+        lm = w / g;
+        ln = grp * p.gn + (w - lm * g);
+    }
+    tm = (xcd % p.xm) * p.rm + lm;
+    tn = (xcd / p.xm) * p.rn + ln;
     return tm < p.tiles_m && tn < p.tiles_n;
 }
 
@@ -82,6 +98,7 @@ inline int plan_tile_map(ConvKernelArgs &k, int BM, int BN) {
         long cost = ((long)rm * BM + (long)rn * BN) * 64 + waste * (BM + BN);
         if (best < 0 || cost < best) { best = cost; k.xm = xm; k.rm = rm; k.rn = rn; }
     }
+    k.gn = std::max(1, std::min(k.gn_req, k.rn));                 // measured per layer by conv_autotune (results do not depend on it)
     return 8 * k.rm * k.rn;
 }
 
