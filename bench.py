@@ -146,7 +146,7 @@ def video_detector_leg(config, B, seed, n_frames, device_overlay=True):
             return out
     vd._pipe = InjectingPipeline(wl.net, wl.ds, CONF_THRES, NMS_THRES, class_mask=CLASS_MASK, cap=512)
     bgr = np.ascontiguousarray(wl.ring[..., ::-1])                    # what a decoder delivers
-    warm = 20 * B                                                     # schedule trial (16 steady-state steps) + ramp, untimed
+    warm = 24 * B                                                     # schedule trial (20 steady-state steps) + ramp, untimed
     cap = _ClipCapture(bgr, warm + n_frames)
     rows = n = 0
     t0 = None
@@ -341,12 +341,12 @@ def main():
 
     def settle_schedule(w, first, host_frames):
         """Set-up, like the conv autotuner's launches at plan time: the pipeline picks its stream schedule BY MEASUREMENT on the caller's
-        first 16 steady-state steps (pipeline.cpp Trial: groups of 4 alternating serialized / two-stream, the faster one kept).  These steps run here,
+        first 20 steady-state steps (pipeline.cpp Trial: groups of 5 alternating serialized / two-stream, the faster one kept).  These steps run here,
         before the W warm-up steps, so that warm-up and timed region both run the settled schedule.  Returns (steps used, record)."""
         n = 0
         if args.schedule != "policy" or w.per_frame * w.batch < 256:     # (smaller ReID passes keep two streams without a trial)
             return 0, None
-        while w.pipe.schedule_trial(host_frames)["decided"] is None and n < 24:
+        while w.pipe.schedule_trial(host_frames)["decided"] is None and n < 32:
             w.step(first + n, prefetch=True, host_frames=host_frames, prefetch2=True)
             n += 1
         if n:                                                     # (leave nothing of the trial in flight across the clock start)
@@ -370,7 +370,7 @@ def main():
             w1.pipe.set_schedule(sched_arg)
             n1 = 0
             if args.schedule == "policy" and w1.per_frame * w1.batch >= 256:
-                while w1.pipe.schedule_trial(False)["decided"] is None and n1 < 24:
+                while w1.pipe.schedule_trial(False)["decided"] is None and n1 < 32:
                     w1.step(n1, prefetch=True)
                     n1 += 1
             k1 = max(3, min(K, 20))
@@ -621,8 +621,8 @@ def main():
                        **({} if solo is None else {"rank0_single": solo,
                                                    "efficiency_vs_rank0_single": round(frames_total / dt / (world * solo["value"]), 4)}),
                        "schedule_trial": None if trial is None else dict(
-                           note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds of three measured steps (the better of two groups, timed "
-                                "inside the step call) under either schedule on this box, per rank; `schedule` is what the timed steps then ran under",
+                           note="stream schedule picked by measurement at set-up (pipeline.cpp Trial): seconds of three measured steps (the better of two groups, wall clock "
+                                "between the returns of the step call) under either schedule on this box, per rank; `schedule` is what the timed steps then ran under",
                            per_rank=trial, with_upload=trial_up, set_up_steps=n_set),
                        **ranks.describe()},
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_with_upload is the PCIe-inclusive rate",

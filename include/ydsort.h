@@ -239,12 +239,12 @@ int yds_pipeline_prefetch_host(yds_pipe *, const uint8_t *frames_host, int h, in
  * the choice).  min_crops >= 0: from that many crops per batch the ReID pass is enqueued on the detector's stream, between
  * the first layers of the next pass and the rest (every conv kernel has the chip to itself); -1: always two streams sharing
  * the CUs; < -1: the built-in policy (round 5: BY MEASUREMENT - for ReID passes of >= 256 crops the pipeline times both schedules on
- * the caller's first 16 steady-state steps (alternating groups of 4) and keeps the faster one; one decision for yds_pipeline_step, one for
+ * the caller's first 20 steady-state steps (alternating groups of 5: two transition steps + three measured) and keeps the faster one; one decision for yds_pipeline_step, one for
  * yds_pipeline_step_host; two streams for smaller passes; env YDS_PIPE_SERIAL overrides; pipeline.cpp `Trial`).
  * yds_pipeline_last_schedule: 1 if the last step ran serialized, else 0.
  * yds_pipeline_schedule_trial: what the trial of an entry (uploaded = 0: yds_pipeline_step, 1: yds_pipeline_step_host) measured -
- * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds the three measured steps of the BETTER of a schedule's two
- * groups spent inside the step call (round 6; rounds 4-5: wall time between returns, both groups summed). */
+ * decided 0 = still measuring, 1 = serialized kept, -1 = two-stream kept; seconds of the three measured steps of the BETTER of a schedule's two
+ * groups, wall clock between the returns of the step call (round 6; rounds 4-5: both groups summed). */
 int yds_pipeline_set_schedule(yds_pipe *, int min_crops);
 /* Byte order of the frames handed to yds_pipeline_step / _step_host: 0 = R, G, B (default: what video_detect.py:33-36 makes of a
  * decoded frame before the detector sees it), 1 = B, G, R as a decoder delivers them - the resize front end and the ReID crops then

@@ -75,12 +75,12 @@ def _run(config, schedule):
 def test_long_stream_ids_bit_exact_vs_reference(config, schedule, name):
     ran, g, trial = _run(config, schedule)
     if name == "policy":
-        # the pipeline timed both schedules on the stream's own steps (4 serialized, then two-stream: pipeline.cpp Trial) - so this run
+        # the pipeline timed both schedules on the stream's own steps (5 serialized, then two-stream: pipeline.cpp Trial) - so this run
         # also crossed from one schedule to the other in the middle of the stream, with identical rows
-        # (groups of 4 steady-state steps alternate serialized / two-stream; 16 steps decide - more than these streams have)
+        # (groups of 5 steady-state steps alternate serialized / two-stream; 20 steps decide - more than these streams have)
         n_steady = int(g["n_frames"]) // B - 1
         assert trial["decided"] is None, trial
-        if n_steady >= 5:                        # cfg2: steps 0-3 serialized, 4-7 two-stream
+        if n_steady >= 6:                        # cfg2: steps 0-4 serialized, 5-6 two-stream
             assert trial["serialized_s"] > 0 and ran == "two-stream", (trial, ran)
     else:
         assert ran == name and trial["decided"] is None

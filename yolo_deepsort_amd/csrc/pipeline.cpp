@@ -250,36 +250,42 @@ public:
     // ---- stream schedule by measurement (round 5) ----------------------------------------------------------------------
     // Which schedule is faster is a property of the box (round 4: serialized +1.2 % on one, two-stream +1.3-3.1 % on four others),
     // so the pipeline times both on the caller's own steps, like conv_autotune times tile variants: steady-state steps (a next
-    // batch handed over, >= 256 crops) run in groups of 1 + TRIAL_STEPS - serialized, two-stream, serialized, two-stream; the first
-    // step of a group absorbs the transition - the time the three measured steps spend INSIDE step() is summed per group, and the schedule
-    // whose better group is smaller is kept (16 steps in all; round 6: see trial_step_done).
+    // batch handed over, >= 256 crops) run in groups of TRIAL_SKIP + TRIAL_STEPS - serialized, two-stream, serialized, two-stream; the first
+    // step of a group absorbs the transition - the wall time of the three measured steps is taken between the returns of step(), and the
+    // schedule whose better group is shorter is kept (20 steps in all; round 6: see trial_step_done).
     // Results do not depend on the schedule (parity tests run both), so the trial is invisible to the caller.  One decision per
     // entry (frames resident in HBM / uploaded inside the step): their balance differs.
     static constexpr int TRIAL_STEPS = 3, TRIAL_GROUPS = 4;      // groups alternate serialized / two-stream: S T S T
+    // unmeasured steps at the head of a group (round 6: two - with ONE the step after a switch still ran short on work the other
+    // schedule had left in flight, and serialized measured 7 % faster in the trial where the steady rates were equal)
+    static constexpr int TRIAL_SKIP = 2, TRIAL_LEN = TRIAL_SKIP + TRIAL_STEPS;
     struct Trial {
         int n = 0;                      // steady-state steps seen
-        double t0 = 0, t_serial = 0, t_two = 0;   // t0: seconds of the running group; t_*: the better group of each schedule (3 measured steps)
+        double t0 = 0, t_serial = 0, t_two = 0;   // t0: start of the running group; t_*: the better group of each schedule (3 measured steps)
         int decided = 0;                // 0 = measuring, 1 = serialized, -1 = two-stream
     };
-    // Schedule of the NEXT ReID pass for an entry while its trial runs.  A group = one transition step + TRIAL_STEPS measured steps;
+    // Schedule of the NEXT ReID pass for an entry while its trial runs.  A group = TRIAL_SKIP transition steps + TRIAL_STEPS measured steps;
     // the groups alternate (serialized first) and each schedule is measured twice, once earlier and once later in the run, so that
     // the clock / temperature drift of the first second under load (the first group ran 7 % faster than steady state on one box)
     // does not decide the comparison.
-    bool trial_wants_serial(const Trial &t) const { return t.decided ? t.decided > 0 : (t.n / (TRIAL_STEPS + 1)) % 2 == 0; }
-    // step_seconds: the time THIS call of step() took (round 6: not the wall time between returns, which charged the caller's own
-    // time between steps - a slow decoder, a consumer rendering - to whichever schedule happened to be on trial); per schedule the
-    // BETTER of its two groups counts (one hiccup inside a three-step group no longer fixes the decision).
-    void trial_step_done(Trial &t, double step_seconds) {
+    bool trial_wants_serial(const Trial &t) const { return t.decided ? t.decided > 0 : (t.n / TRIAL_LEN) % 2 == 0; }
+    // A group is timed by the wall clock between the RETURNS of step() - the steady-state period, which is what the schedules differ in
+    // (round 6 first timed the seconds spent INSIDE step(): that is not the period - the serialized schedule returns earlier relative to
+    // the device's work - and it preferred serialized by 8 % where the frame rates were equal; profiles/r06_bench_cfg3.json of that tree).
+    // Per schedule the BETTER of its two groups counts (round 6): one hiccup of the caller inside a three-step group - a slow
+    // decoder, a consumer rendering - no longer fixes the decision; a steadily slow caller stretches both schedules alike.
+    void trial_step_done(Trial &t) {
+        using clk = std::chrono::steady_clock;
         if (t.decided) return;
-        const int group = t.n / (TRIAL_STEPS + 1), k = t.n % (TRIAL_STEPS + 1);
-        if (k == 0) t.t0 = 0;                                     // the group's transition step: not measured
-        else t.t0 += step_seconds;
-        if (k == TRIAL_STEPS) {
+        const double now = std::chrono::duration<double>(clk::now().time_since_epoch()).count();
+        const int group = t.n / TRIAL_LEN, k = t.n % TRIAL_LEN;
+        if (k == TRIAL_SKIP - 1) t.t0 = now;                      // the group's transition steps have returned
+        if (k == TRIAL_LEN - 1) {
             double &best = group % 2 == 0 ? t.t_serial : t.t_two;
-            best = best > 0 ? std::min(best, t.t0) : t.t0;
+            best = best > 0 ? std::min(best, now - t.t0) : now - t.t0;
         }
         ++t.n;
-        if (t.n == TRIAL_GROUPS * (TRIAL_STEPS + 1)) t.decided = t.t_serial <= t.t_two ? 1 : -1;
+        if (t.n == TRIAL_GROUPS * TRIAL_LEN) t.decided = t.t_serial <= t.t_two ? 1 : -1;
     }
 
     void step(const uint8_t *frames_dev, const uint8_t *next_frames_dev, int next_inject_set, int h, int w, int batch, int32_t *out6,
@@ -396,7 +402,7 @@ public:
         auto t_end = clk::now();
         stage_us[2] = us(t_begin, t_nms); stage_us[3] = us(t_nms, t_reid); stage_us[4] = us(t_reid, t_end);
         // a steady-state step of a chip-filling ReID pass counts towards the schedule trial of its entry
-        if (!forced && next_frames_dev && D_all >= 256) trial_step_done(trial, std::chrono::duration<double>(t_end - t_begin).count());
+        if (!forced && next_frames_dev && D_all >= 256) trial_step_done(trial);
     }
 
     Darknet *net;

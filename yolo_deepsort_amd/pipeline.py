@@ -73,7 +73,7 @@ class Pipeline:
 
     def schedule_trial(self, uploaded=False):
         """What the pipeline's schedule trial measured for an entry (frames resident in HBM / uploaded inside the step):
-        dict(decided="serialized" | "two-stream" | None while measuring, serialized_s, two_stream_s: seconds of three measured steps, the better of each schedule's two groups, timed inside step())."""
+        dict(decided="serialized" | "two-stream" | None while measuring, serialized_s, two_stream_s: seconds of three measured steps, the better of each schedule's two groups, wall clock between returns of step())."""
         d, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
         _lib.check(_lib.load().yds_pipeline_schedule_trial(self._h, 1 if uploaded else 0, C.byref(d), C.byref(a), C.byref(b)))
         return dict(decided={1: "serialized", -1: "two-stream"}.get(d.value), serialized_s=a.value, two_stream_s=b.value)
