@@ -276,3 +276,35 @@ def test_default_batching_and_device_output_stage_vs_reference_generator(tmp_pat
 def VideoDetectorAuto():
     from yolo_deepsort_amd.detect import VideoDetector
     return VideoDetector
+
+
+def test_callable_extractor_and_default_arguments_take_the_frame_by_frame_loop(tmp_path):
+    """`DeepSort(extractor_callable, ...)` (deep_sort.py accepts any callable on a list of crops) with VideoDetector's DEFAULT
+    arguments on a file-like source: the default read-ahead must not route it into the batched device pipeline (which drives the package's
+    own Extractor and tracker handles) - the frame-by-frame loop runs, calls the callable once per processed frame, and yields what the
+    reference's generator yielded."""
+    from yolo_deepsort_amd.deep_sort import DeepSort, Extractor
+    from yolo_deepsort_amd.workload import DS_PARAMS
+    from yolo_deepsort_amd import synth
+    g = golden("video_detect")
+    case = "tracker_every_frame"
+    c, sc, net, frames, inj, _, act, VideoDetector, cfgs = _build(case, 1)
+    ex, calls = Extractor(synth.reid_state_dict(0)), []
+
+    def embed(crops):                                        # a user's extractor: any callable crops -> [n, 512]
+        calls.append(len(crops))
+        return ex(crops)
+    tracker = DeepSort(embed, use_cuda=True, **DS_PARAMS)
+    vd = VideoDetector(net, _names(tmp_path, cfgs), thres=sc["thres"], nms_thres=sc["nms_thres"], skip_frames=c["skip_frames"],
+                       class_mask=c["class_mask"], tracker=tracker, action_id=act)
+    assert vd.batch_frames is None and not vd._batchable()
+    index = {_key(f): t for t, f in enumerate(frames)}
+    orig = vd.image_detector.detect
+
+    def detect(frame):
+        net.set_injection(0, inj[index[_key(frame)]])
+        return orig(frame)
+    vd.image_detector.detect = detect
+    yields = list(vd.detect(Capture(frames[..., ::-1], sc["fps"]), skip_secs=c["skip_secs"], show_fps=False))
+    _compare(case, c, g, yields)
+    assert vd._pipe is None and len(calls) > 0 and all(n > 0 for n in calls)
