@@ -36,6 +36,7 @@ result rows ({count, rows[256][6]} per frame, RCCL through libydsort's yds_comm_
 """
 
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -163,9 +164,12 @@ def video_detector_leg(config, B, seed, n_frames, device_overlay=True):
     u = vd.host_us
     per = {"engine: " + k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_frames", "step", "wait_consumer")}
     per.update({"consumer: " + k: round(u[k] / max(u["frames"], 1), 1) for k in ("wait_engine", "overlay")})
-    return (n - warm) / dt, dict(us_per_frame_by_thread=per, frames=n - warm, tracker_rows=rows, batch_frames=vd._batch_now,
-                                 output_stage="device (csrc/overlay.hip)" if vd.device_overlay else "host (numpy LabelDrawer)",
-                                 schedule=vd._pipe.last_schedule())
+    rec_schedule, rec_batch, rec_overlay = vd._pipe.last_schedule(), vd._batch_now, vd.device_overlay
+    del vd, wl, cap
+    gc.collect()                                                      # (this leg's workload off the device before the next leg builds its own)
+    return (n - warm) / dt, dict(us_per_frame_by_thread=per, frames=n - warm, tracker_rows=rows, batch_frames=rec_batch,
+                                 output_stage="device (csrc/overlay.hip)" if rec_overlay else "host (numpy LabelDrawer)",
+                                 schedule=rec_schedule)
 
 
 def conv_roofline(variants, peak):
@@ -278,10 +282,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100, help="timed steps (100 x 32 frames = 2 s of the pipeline: long enough for external samplers such as rocm-smi to land inside the timed region)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=None, help="frames per step (detector batch).  Default by config (workload.DEFAULT_BATCH): 68 for cfg2 / cfg3 / cfg4 since round 6 - "
+    ap.add_argument("--batch", type=int, default=None, help="frames per step (detector batch).  Default (workload.DEFAULT_BATCH): 68 for every config since round 6 - "
                                                               "the 19x19 layers of a 32-frame batch are 368 window tiles for 256 CUs (1.44 rounds, a quarter of the second "
-                                                              "round idle), 768 = 3.0 rounds at 68 frames: +4..5 %% end to end (profiles/r06_batch_sweep.txt); 32 for cfg5, whose ReID pass "
-                                                              "of 4800 crops per 32 frames already fills the chip (64: -1.4 %%); 32 = rounds 4-5, 16 = rounds 1-3")
+                                                              "round idle), 768 = 3.0 rounds at 68 frames: +4..5 %% end to end, +2.3 %% on the crowd stream (profiles/r06_batch_sweep.txt); "
+                                                              "32 = rounds 4-5, 16 = rounds 1-3")
     ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = BASELINE configs[1] (the metric's configuration); cfg4 = configs[3]: yolov4 + DeepSORT, one stream per GPU (seeds = rank)")
     ap.add_argument("--seed-base", type=int, default=0, help="stream seed of rank r = seed-base + r")
@@ -386,6 +390,7 @@ def main():
                         note="rank 0 alone before the communicator formed: same workload construction and steps on a workload of its own, "
                              "no exchange step, the other GPUs idle")
             del w1
+            gc.collect()                                               # (the handles sit in reference cycles: free the device buffers NOW - a crowd workload is ~80 GB)
             sync()
         ranks.barrier()            # (host group: the communicator does not exist yet)
     ranks.connect()                # RCCL communicator on the bound device (N > 1)
@@ -505,6 +510,7 @@ def main():
         dt1a, _ = timed_steps(wl1, ranks, sync, n1, 20, n1 + 20, host_frames=False, lookahead=True)
         fbf, fbf_ahead = ranks.total_frames(n1, 1) / dt1, ranks.total_frames(n1, 1) / dt1a
         del wl1
+        gc.collect()                                               # (the handles sit in reference cycles: free the device buffers NOW - a crowd workload is ~80 GB)
         sync()
 
     # ---- the generator: VideoDetector.detect as the unchanged demo drives it (default arguments, shim import paths, BGR result images)
@@ -522,6 +528,7 @@ def main():
     f32_fps, roofline_f32 = None, None
     if not args.no_extras and not args.half and math_name != "f32":
         del wl
+        gc.collect()                                               # (the handles sit in reference cycles: free the device buffers NOW - a crowd workload is ~80 GB)
         sync()
         lib.yds_set_conv_math(0)
         wl32 = Workload(args.config, B, seed=ranks.stream_seed(args.seed_base))
@@ -543,6 +550,7 @@ def main():
                 roofline_f32["schedule"] = "serialized (diagnostic leg); value_f32_math ran under " + sched32
                 roofline_f32["schedule_trial"] = trial32
         del wl32
+        gc.collect()                                               # (the handles sit in reference cycles: free the device buffers NOW - a crowd workload is ~80 GB)
         lib.yds_set_conv_math(1)
 
     # ---- Darknet.half() (ImageDetector(half=True), img_detect.py:49-50): single-term fp16 operands AND 2-byte activations in the
@@ -569,6 +577,7 @@ def main():
         else:
             half_err = "; ".join(f"rank {r}: {v}" for r, v in enumerate(votes) if v is not None)[:300]
         del wlh
+        gc.collect()                                               # (the handles sit in reference cycles: free the device buffers NOW - a crowd workload is ~80 GB)
         sync()
 
     # ---- the un-injected leg (SURVEY 8d "Weights"): real .weights / ckpt.t7 files, nothing written into the head tensors
@@ -601,6 +610,7 @@ def main():
         elif real_err is None or any(v is not None for v in votes):
             real_err = "; ".join(f"rank {r}: {v}" for r, v in enumerate(votes) if v is not None)[:300]
         del wlr
+        gc.collect()                                               # (the handles sit in reference cycles: free the device buffers NOW - a crowd workload is ~80 GB)
         sync()
 
     cpu = None

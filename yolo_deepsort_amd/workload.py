@@ -21,8 +21,9 @@ CONFIGS = {
 # frames per step of bench.py (profiles/r06_batch_sweep.txt).  68 for the 608 x 608 detectors: one workgroup per CU and 256-pixel tiles make a
 # layer's time a step function of its tile count, and 68 x 361 = 24 548 pixels of a 19 x 19 map are 95.9 -> 96 tiles of 256: x 8 filter tiles
 # = 768 = exactly 3 rounds on 256 CUs (38 x 38: 384 x 4 = 6.0 rounds, 76 x 76: 1535 x 2 = 11.99) - at 64 frames they are 2.84 / 5.64 / 11.3,
-# at 32 (rounds 4-5) 1.44 / 2.83 / 5.64.  cfg5's 4800-crop ReID pass fills the chip at 32 frames already (64: -1.4 %, 34: equal).
-DEFAULT_BATCH = {"cfg2": 68, "cfg3": 68, "cfg4": 68, "cfg5": 32}
+# at 32 (rounds 4-5) 1.44 / 2.83 / 5.64.  cfg5 (4800 crops per 32 frames: its ReID pass alone fills the chip) gains less: 64 frames -1.4 %,
+# 34 equal, 68 +2.3 % (667 -> 682 frames/s on one box).
+DEFAULT_BATCH = {"cfg2": 68, "cfg3": 68, "cfg4": 68, "cfg5": 68}
 DS_PARAMS = dict(max_dist=0.3, nn_budget=30, n_init=3, max_iou_distance=0.7, max_age=30)   # video_deepsort.py:18-25
 IMG = 608
 CONF_THRES, NMS_THRES, CLASS_MASK = 0.5, 0.4, [0, 2, 4]
