@@ -1320,6 +1320,135 @@ def gen_wide_range(ns):
     _save("wide_range", **arrays)
 
 
+WIDE_CSP_CFG = """
+[net]
+channels=3
+height=64
+width=64
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=mish
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=2
+pad=1
+activation=mish
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=mish
+
+[route]
+layers = -2
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=mish
+
+[convolutional]
+batch_normalize=1
+filters=32
+size=1
+stride=1
+pad=1
+activation=mish
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=mish
+
+[shortcut]
+from=-3
+activation=linear
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=mish
+
+[route]
+layers = -1,-7
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=1
+stride=1
+pad=1
+activation=mish
+
+[convolutional]
+batch_normalize=1
+filters=128
+size=3
+stride=2
+pad=1
+activation=mish
+
+[route]
+layers=-1
+groups=2
+group_id=1
+
+[convolutional]
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=255
+activation=linear
+
+[yolo]
+mask = 0,1,2
+anchors = 10,14,  23,27,  37,58,  81,82,  135,169,  344,319
+classes=80
+num=6
+"""
+
+
+def gen_wide_mish(ns):
+    """The yolov4 constructs under the wide BatchNorm statistics (round 6, after gen_wide_range): Mish everywhere, a CSP split (two 1x1
+    convolutions reading one tensor - merged into one launch by the planner), a shortcut, a two-source route and a grouped route;
+    random / all-black / saturated inputs; every conv block sampled + the decoded head."""
+    import torch
+    model, _ = _ref_darknet_profile(ns, WIDE_CSP_CFG, (64, 64), WIDE_SEED + 2, -1.0)
+    x = wide_inputs(64, seed=3)
+    y, lay = _layer_samples(model, torch, x, 1024, 300)
+    print("    CSP / Mish net: out", y.shape, "finite", bool(np.isfinite(y).all()),
+          "layer |x| max", [round(float(lay[k.replace('_idx', '_absmax')]), 2) for k in lay if k.endswith("_idx")])
+    _save("wide_range_mish", out=y, **lay)
+
+
 def _ref_darknet_profile(ns, cfg_text, img_size, seed, obj_bias):
     import torch
     cfg_path = _tmp_write(cfg_text, ".cfg")
@@ -1333,7 +1462,7 @@ def _ref_darknet_profile(ns, cfg_text, img_size, seed, obj_bias):
 
 
 
-ALL = dict(long_stream=gen_long_stream, wide=gen_wide_range, rect=gen_rect, video_detect=gen_video_detect, action=gen_action, bench_shape=gen_bench_shape, options=gen_track_options, tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
+ALL = dict(long_stream=gen_long_stream, wide=gen_wide_range, wide_mish=gen_wide_mish, rect=gen_rect, video_detect=gen_video_detect, action=gen_action, bench_shape=gen_bench_shape, options=gen_track_options, tiled=gen_tiled, cfg_parse=gen_cfg_parse, mini=gen_mini_darknet, tiny416=gen_tiny416, full608=gen_full608,
            nms=gen_nms, plumbing=gen_detect_plumbing, reid=gen_reid, kalman=gen_kalman,
            traces=gen_track_traces)
 

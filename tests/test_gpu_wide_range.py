@@ -74,6 +74,24 @@ def test_residual_net_every_conv_block_and_heads(mode):
 
 
 @pytest.mark.parametrize("mode", [1, 0], ids=["f16x3", "f32"])
+def test_mish_csp_net_every_conv_block_and_heads(mode):
+    """The yolov4 constructs under the wide statistics: Mish in every epilogue, the CSP split (two 1x1 convolutions of one tensor, merged
+    into one launch by the planner), a fused shortcut, a two-source route and a grouped route (tests/golden/wide_range_mish.npz)."""
+    from oracle.gen_golden import WIDE_CSP_CFG, WIDE_SEED, wide_inputs
+    g = golden("wide_range_mish")
+
+    def run():
+        net = _net(WIDE_CSP_CFG, 64, WIDE_SEED + 2)
+        out = net(wide_inputs(64, seed=3))
+        worst = dict(abs=0.0, rel=0.0)
+        assert _check_layers(net, g, "", 3, worst) >= 8
+        assert np.isfinite(out).all()
+        np.testing.assert_allclose(out, g["out"], rtol=RTOL, atol=ATOL)
+        print("CSP / Mish net, math", mode, "worst conv-block error", worst, "heads max abs", float(np.abs(out - g["out"]).max()))
+    _with_math(mode, run)
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["f16x3", "f32"])
 def test_tiny416_conv_blocks_and_heads(mode):
     from oracle.gen_golden import WIDE_SEED, wide_inputs
     g = golden("wide_range")

@@ -206,3 +206,22 @@ def test_wide_range_fixture_vs_oracle_restatement():
         n += 1
     assert n == 12
     np.testing.assert_allclose(out, g["res_out"], rtol=RTOL, atol=ATOL)
+
+
+def test_wide_range_mish_csp_fixture_vs_oracle_restatement():
+    """The yolov4 constructs (Mish, CSP split, shortcut, two-source and grouped routes) under the wide BatchNorm statistics:
+    tests/golden/wide_range_mish.npz, computed by the imported reference."""
+    from oracle.gen_golden import WIDE_CSP_CFG, WIDE_SEED, wide_inputs
+    g = golden("wide_range_mish")
+    net = DarknetOracle(WIDE_CSP_CFG, (64, 64), is_text=True)
+    blob = synth.darknet_weights_blob(WIDE_CSP_CFG, WIDE_SEED + 2, -1.0, profile="wide")
+    w = np.frombuffer(blob, dtype=F32, offset=20)
+    assert net.load_weights_array(w) == w.size
+    out = net.forward(wide_inputs(64, seed=3), keep_layers=True)
+    n = 0
+    for key in [k for k in g.files if k.startswith("L") and k.endswith("_idx")]:
+        i = int(key[1:-4])
+        np.testing.assert_allclose(net.layer_outputs[i].reshape(-1)[g[key]], g[f"L{i}_val"], rtol=1e-4, atol=1e-4, err_msg=key)
+        n += 1
+    assert n == 11
+    np.testing.assert_allclose(out, g["out"], rtol=RTOL, atol=ATOL)
